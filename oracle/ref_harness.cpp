@@ -1,0 +1,411 @@
+// TEST INFRASTRUCTURE ONLY — harness around the UNMODIFIED reference sources.
+//
+// The two reference programs are textually included (from where they lie under the
+// reference checkout; nothing is copied) into separate namespaces, with `main` renamed by
+// the preprocessor.  The scene each program builds on the stack of its main()
+// (/root/reference/main.cpp:473-607, next_event.cpp:605-689) is borrowed through the boost
+// shim's thread-launch hook, so scene constants are never restated here.  All randomness
+// comes from the linker-wrapped rand() in ref_rt.cpp.
+//
+// Build recipe: oracle/Makefile (outputs only under oracle/_ref/).
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+
+#include "ptor_rt.h"
+#include "ptor_types.h"
+#include "shim/ptor_boost_shim.hpp"
+
+#ifndef PTOR_REF_MAIN
+#error "define PTOR_REF_MAIN / PTOR_REF_NEE / PTOR_REF_BRDF as quoted paths into the reference checkout"
+#endif
+
+namespace ref_pt {
+#define main ref_main
+#include PTOR_REF_MAIN
+#undef main
+}  // namespace ref_pt
+
+namespace ref_nee {
+#define main ref_main
+#include PTOR_REF_NEE
+#undef main
+}  // namespace ref_nee
+
+namespace ref_brdf {
+#include PTOR_REF_BRDF
+}
+
+namespace {
+
+struct PT {
+    enum { prog = 0 };
+    typedef ref_pt::V3 V3;
+    typedef ref_pt::Ray Ray;
+    typedef ref_pt::Scene Scene;
+    typedef ref_pt::Renderer Renderer;
+    typedef ref_pt::Body Body;
+    typedef ref_pt::Shape Shape;
+    typedef ref_pt::Plane Plane;
+    typedef ref_pt::Sphere Sphere;
+    typedef ref_pt::Material Material;
+    typedef ref_pt::Chrome Chrome;
+    typedef ref_pt::Glass Glass;
+    typedef ref_pt::Camera Camera;
+    static int run_main(int argc, const char** argv) { return ref_pt::ref_main(argc, argv); }
+    static void save(V3* b, int s, int w, int h) { ref_pt::save(b, s, w, h); }
+};
+
+struct NEE {
+    enum { prog = 1 };
+    typedef ref_nee::V3 V3;
+    typedef ref_nee::Ray Ray;
+    typedef ref_nee::Scene Scene;
+    typedef ref_nee::Renderer Renderer;
+    typedef ref_nee::Body Body;
+    typedef ref_nee::Shape Shape;
+    typedef ref_nee::Plane Plane;
+    typedef ref_nee::Sphere Sphere;
+    typedef ref_nee::Material Material;
+    typedef ref_nee::Chrome Chrome;
+    typedef ref_nee::Glass Glass;
+    typedef ref_nee::Camera Camera;
+    static int run_main(int argc, const char** argv) { return ref_nee::ref_main(argc, argv); }
+    static void save(V3* b, int s, int w, int h) { ref_nee::save(b, s, w, h); }
+};
+
+std::function<void(void*)> g_session;
+std::string g_scratch = "/tmp";
+
+bool session_hook(const ptor::Launch& l) {
+    if (g_session) g_session(l.scene);
+    return true;  // never run the reference worker from a session
+}
+
+struct CoutSilencer {
+    std::streambuf* old;
+    std::ostringstream sink;
+    CoutSilencer() { old = std::cout.rdbuf(sink.rdbuf()); }
+    ~CoutSilencer() { std::cout.rdbuf(old); }
+};
+
+struct ChdirScratch {
+    char old[4096];
+    bool ok;
+    ChdirScratch() {
+        ok = getcwd(old, sizeof old) != 0;
+        if (chdir(g_scratch.c_str()) != 0) ok = false;
+    }
+    ~ChdirScratch() {
+        if (ok && chdir(old) != 0) {}
+    }
+};
+
+// Run `fn(Scene*)` while the reference's main() of program T is alive with its scene built.
+template <class T>
+void with_scene(const std::function<void(typename T::Scene*)>& fn) {
+    static bool registered = false;
+    if (!registered) {
+        registered = true;
+        typedef typename T::Ray (*getray_fp)(typename T::Camera*, double, double);
+        typedef typename T::V3 (*iadd_fp)(typename T::V3*, typename T::V3);
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wpmf-conversions"
+        void* a = (void*)(getray_fp)(&T::Camera::getRay);
+        void* b = (void*)(iadd_fp)(&T::V3::iadd);
+#pragma GCC diagnostic pop
+        ptor_rt_register(T::prog, a, b);
+    }
+    CoutSilencer quiet;
+    ChdirScratch cd;
+    g_session = [&](void* s) { fn((typename T::Scene*)s); };
+    ptor::thread_hook = &session_hook;
+    const char* argv[] = {"ref", "2", "2", "1", "1"};
+    ptor_rt_mode_seq(1, 0);  // main()'s own save() etc. draw nothing, but keep the wrap defined
+    T::run_main(5, argv);
+    ptor::thread_hook = 0;
+    g_session = nullptr;
+}
+
+template <class V>
+void put3(double* d, const V& v) {
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+
+template <class T>
+int scene_bodies(ptor_body* out, int cap, ptor_camera* cam) {
+    int count = 0;
+    with_scene<T>([&](typename T::Scene* s) {
+        count = s->body_count;
+        put3(cam->origin, s->camera.origin);
+        put3(cam->topleft, s->camera.topleft);
+        put3(cam->topright, s->camera.topright);
+        put3(cam->bottomleft, s->camera.bottomleft);
+        for (int i = 0; i < s->body_count && i < cap; i++) {
+            typename T::Body* b = s->objects[i];
+            ptor_body o;
+            memset(&o, 0, sizeof o);
+            o.brdf_id = -1;
+            if (typename T::Plane* p = dynamic_cast<typename T::Plane*>(b->shape)) {
+                o.shape = PTOR_PLANE;
+                put3(o.center, p->center);
+                put3(o.normal, p->normal);
+            } else if (typename T::Sphere* sp = dynamic_cast<typename T::Sphere*>(b->shape)) {
+                o.shape = PTOR_SPHERE;
+                put3(o.center, sp->center);
+                o.radius = sp->radius;
+            } else {
+                o.shape = -1;
+            }
+            if (typename T::Glass* gl = dynamic_cast<typename T::Glass*>(b->material)) {
+                o.material = PTOR_GLASS;
+                o.ior = gl->ior;
+                o.reflection = gl->reflection;
+            } else if (dynamic_cast<typename T::Chrome*>(b->material)) {
+                o.material = PTOR_CHROME;
+            } else {
+                o.material = PTOR_DIFFUSE;
+            }
+            put3(o.color, b->material->color);
+            put3(o.emission, b->material->emission);
+            out[i] = o;
+        }
+    });
+    return count;
+}
+
+template <class T>
+typename T::Ray make_ray(const double* r) {
+    return typename T::Ray(typename T::V3(r[0], r[1], r[2]), typename T::V3(r[3], r[4], r[5]));
+}
+
+template <class T>
+int intersect_all(const double* rays6, int n, double* t_out) {
+    int count = 0;
+    with_scene<T>([&](typename T::Scene* s) {
+        count = s->body_count;
+        for (int i = 0; i < n; i++) {
+            typename T::Ray ray = make_ray<T>(rays6 + 6 * i);
+            for (int b = 0; b < count; b++) t_out[(size_t)i * count + b] = s->objects[b]->shape->intersect(ray);
+        }
+    });
+    return count;
+}
+
+template <class T>
+void set_mode(int mode, uint64_t seed, const int* script, int script_len) {
+    if (mode == PTOR_MODE_SCRIPT)
+        ptor_rt_mode_script(script, script_len);
+    else if (mode == PTOR_MODE_PIXEL)
+        ptor_rt_mode_pixel(seed);
+    else
+        ptor_rt_mode_seq(seed, 0);
+}
+
+template <class T>
+long long render(int W, int H, int first_it, int n_it, int mode, uint64_t seed, const int* script,
+                 int script_len, double* buffer_out) {
+    long long draws = 0;
+    with_scene<T>([&](typename T::Scene* s) {
+        typename T::Scene sc = *s;
+        sc.width = W;
+        sc.height = H;
+        typename T::Renderer r(sc);
+        set_mode<T>(mode, seed, script, script_len);
+        for (int it = first_it; it < first_it + n_it; it++) {
+            ptor_rt_begin_iteration((uint32_t)it);
+            r.iterate();
+        }
+        draws = ptor_rt_draws();
+        for (int i = 0; i < W * H; i++) put3(buffer_out + 3 * (size_t)i, r.buffer[i]);
+    });
+    return draws;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptor_set_scratch(const char* dir) {
+    g_scratch = dir;
+    return 0;
+}
+
+// prog: 0 = main.cpp, 1 = next_event.cpp.  Returns body count.
+int ptor_scene_bodies(int prog, ptor_body* out, int cap, ptor_camera* cam) {
+    return prog == 0 ? scene_bodies<PT>(out, cap, cam) : scene_bodies<NEE>(out, cap, cam);
+}
+
+// t_out[n][body_count]: Shape::intersect of every body, in array order. Returns body count.
+int ptor_intersect_all(int prog, const double* rays6, int n, double* t_out) {
+    return prog == 0 ? intersect_all<PT>(rays6, n, t_out) : intersect_all<NEE>(rays6, n, t_out);
+}
+
+// Nearest hit as decided by the reference's own scan loop (next_event.cpp:496-507): trace()
+// entered at depth 4 scans once, records (offset point, body) and returns at depth 5.
+// idx[i] = -1 on a miss.  point3 receives the recorded (offset) point.  The bounce it performs
+// consumes scripted draws (all RAND_MAX/2).
+int ptor_nearest_nee(const double* rays6, int n, int* idx, double* point3) {
+    with_scene<NEE>([&](NEE::Scene* s) {
+        NEE::Scene sc = *s;
+        sc.width = 1;
+        sc.height = 1;
+        NEE::Renderer r(sc);
+        int half[3] = {RAND_MAX / 2, RAND_MAX / 3, RAND_MAX / 5};
+        for (int i = 0; i < n; i++) {
+            ptor_rt_mode_script(half, 3);
+            std::vector<ref_nee::HitRecord> hits;
+            r.trace(make_ray<NEE>(rays6 + 6 * i), 4, &hits);
+            idx[i] = -1;
+            if (!hits.empty()) {
+                for (int b = 0; b < sc.body_count; b++)
+                    if (sc.objects[b] == hits[0].target) idx[i] = b;
+                put3(point3 + 3 * i, hits[0].point);
+            }
+        }
+    });
+    return 0;
+}
+
+// Camera::getRay (main.cpp:154-157) for n (x,y) pairs -> rays6.
+int ptor_get_rays(int prog, const double* xy, int n, double* rays6) {
+    auto body = [&](auto* s) {
+        for (int i = 0; i < n; i++) {
+            auto ray = s->camera.getRay(xy[2 * i], xy[2 * i + 1]);
+            put3(rays6 + 6 * i, ray.origin);
+            put3(rays6 + 6 * i + 3, ray.direction);
+        }
+    };
+    if (prog == 0)
+        with_scene<PT>([&](PT::Scene* s) { body(s); });
+    else
+        with_scene<NEE>([&](NEE::Scene* s) { body(s); });
+    return 0;
+}
+
+// material->bounce(ray, normal) of body `body` with scripted draws. Returns draws consumed.
+int ptor_bounce(int prog, int body, const double* ray6, const double* normal3, const int* script,
+                int script_len, double* out3) {
+    long long draws = 0;
+    auto run = [&](auto* s, auto tag) {
+        typedef decltype(tag) T;
+        ptor_rt_mode_script(script, script_len);
+        typename T::V3 d = s->objects[body]->material->bounce(
+            make_ray<T>(ray6), typename T::V3(normal3[0], normal3[1], normal3[2]));
+        put3(out3, d);
+        draws = ptor_rt_draws();
+    };
+    if (prog == 0)
+        with_scene<PT>([&](PT::Scene* s) { run(s, PT()); });
+    else
+        with_scene<NEE>([&](NEE::Scene* s) { run(s, NEE()); });
+    return (int)draws;
+}
+
+// Full frames through the reference's own Renderer::iterate(). buffer_out[W*H*3] receives the
+// Renderer's private buffer after n_it iterations. Returns the number of rand() calls.
+long long ptor_render(int prog, int W, int H, int first_it, int n_it, int mode, uint64_t seed,
+                      const int* script, int script_len, double* buffer_out) {
+    return prog == 0 ? render<PT>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out)
+                     : render<NEE>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out);
+}
+
+// Renderer::trace of main.cpp (main.cpp:367-405) for n rays, each with its own PIXEL stream
+// (seed, iteration, index i). rgb_out[n][3].
+int ptor_trace_pt(const double* rays6, int n, uint64_t seed, int iteration, double* rgb_out) {
+    with_scene<PT>([&](PT::Scene* s) {
+        PT::Scene sc = *s;
+        sc.width = 1;
+        sc.height = 1;
+        PT::Renderer r(sc);
+        for (int i = 0; i < n; i++) {
+            ptor_rt_mode_stream(seed, (uint32_t)iteration, 0 /* PIXEL domain */, (uint32_t)i);
+            put3(rgb_out + 3 * i, r.trace(make_ray<PT>(rays6 + 6 * i), 0));
+        }
+    });
+    return 0;
+}
+
+// The reference's save() (main.cpp:408-434 / next_event.cpp:533-554) on a caller buffer.
+// The file is written into the scratch directory under the reference's own name;
+// name_out receives that name.
+int ptor_save(int prog, const double* buffer, int samples, int W, int H, char* name_out, int cap) {
+    CoutSilencer quiet;
+    ChdirScratch cd;
+    if (prog == 0) {
+        std::vector<ref_pt::V3> b(W * H);
+        for (int i = 0; i < W * H; i++) b[i] = ref_pt::V3(buffer[3 * i], buffer[3 * i + 1], buffer[3 * i + 2]);
+        ref_pt::save(b.data(), samples, W, H);
+        snprintf(name_out, cap, "output_%d.ppm", samples);
+    } else {
+        std::vector<ref_nee::V3> b(W * H);
+        for (int i = 0; i < W * H; i++) b[i] = ref_nee::V3(buffer[3 * i], buffer[3 * i + 1], buffer[3 * i + 2]);
+        ref_nee::save(b.data(), samples, W, H);
+        snprintf(name_out, cap, "output.ppm");
+    }
+    return 0;
+}
+
+// MatusikBRDF::lookup_brdf_val (MatusikBRDF.h:50-80) on a table file in the reference format.
+int ptor_brdf_lookup(const char* file, const double* angles4, int n, double* rgb_out) {
+    ref_brdf::MatusikBRDF brdf;
+    if (!brdf.read_brdf(std::string(file))) return -1;
+    for (int i = 0; i < n; i++) {
+        const double* a = angles4 + 4 * i;
+        brdf.lookup_brdf_val(a[0], a[1], a[2], a[3], rgb_out[3 * i], rgb_out[3 * i + 1], rgb_out[3 * i + 2]);
+    }
+    return 0;
+}
+
+// CPU baseline: `threads` independent workers, each with its own Renderer and its own
+// sequential rand() stream (what per-thread rand state gives on the author's platform),
+// each running `iters_per_thread` full frames of the reference's iterate(). Returns seconds.
+double ptor_time_iterate(int prog, int W, int H, int iters_per_thread, int threads, uint64_t seed,
+                         double* checksum) {
+    double secs = 0.0;
+    auto run = [&](auto* s, auto tag) {
+        typedef decltype(tag) T;
+        typename T::Scene sc = *s;
+        sc.width = W;
+        sc.height = H;
+        std::vector<double> sums(threads, 0.0);
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> pool;
+        for (int k = 0; k < threads; k++) {
+            pool.emplace_back([&, k]() {
+                typename T::Renderer r(sc);
+                ptor_rt_mode_seq(seed, (uint32_t)k);
+                for (int it = 0; it < iters_per_thread; it++) r.iterate();
+                double acc = 0.0;
+                for (int i = 0; i < W * H; i++) acc += r.buffer[i].x + r.buffer[i].y + r.buffer[i].z;
+                sums[k] = acc;
+            });
+        }
+        for (auto& th : pool) th.join();
+        secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double tot = 0.0;
+        for (double v : sums) tot += v;
+        if (checksum) *checksum = tot;
+    };
+    if (prog == 0)
+        with_scene<PT>([&](PT::Scene* s) { run(s, PT()); });
+    else
+        with_scene<NEE>([&](NEE::Scene* s) { run(s, NEE()); });
+    return secs;
+}
+
+}  // extern "C"
