@@ -1,0 +1,169 @@
+/* ptgpu — C ABI of the MI355X path-tracing / next-event-estimation estimator.
+ *
+ * Drop-in boundary for the per-pixel radiance estimator of Melraidin/path_tracer.  The
+ * reference has no FFI of its own: its seam is the `Renderer` class inside each program
+ * (main.cpp:330-406, next_event.cpp:347-531) plus the process command line.  Each entry point
+ * below names the reference interface it replaces.  Plain pointers and sizes only; every
+ * function returns PT_OK (0) or a negative pt_status and never calls exit().
+ *
+ * Memory: `accum` buffers are W*H*3 doubles, row-major, top row first, RGB interleaved —
+ * the layout of the reference's `V3* buffer` (main.cpp:333,339,609).  Renders ADD into them,
+ * like Renderer::iterate() (main.cpp:362).
+ *
+ * A handle is not thread-safe; use one handle per host thread and per GPU.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument */
+    PT_ERR_DEVICE = -2,    /* HIP call failed */
+    PT_ERR_NOMEM = -3,
+    PT_ERR_IO = -4,
+    PT_ERR_UNSUPPORTED = -5
+} pt_status;
+
+enum { PT_SPHERE = 0, PT_PLANE = 1 };                              /* Sphere main.cpp:198, Plane main.cpp:171 */
+enum { PT_DIFFUSE = 0, PT_CHROME = 1, PT_GLASS = 2, PT_MEASURED = 3 }; /* Material :230, Chrome :257, Glass :269,
+                                                                      MatusikBRDF.h:37 */
+enum { PT_EST_PT = 0, PT_EST_NEE = 1 };                            /* main.cpp trace() / next_event.cpp iterate() */
+
+/* Scene flags */
+#define PT_F_LIGHT_TRUE_CENTER 1u /* NEE shadow rays start at the light's real centre.  Default (flag
+                                     clear) reproduces next_event.cpp:167,406-407, where
+                                     light->shape->center reads the never-assigned base member (0,0,0). */
+
+/* One Body (main.cpp:309-318): a Shape plus a Material, by value.
+ * `normal` is the Plane constructor ARGUMENT (main.cpp:176-179); the library normalises it the way
+ * the constructor does.  `radius` is the Sphere constructor argument (main.cpp:204-208). */
+typedef struct pt_body {
+    int32_t shape;    /* PT_SPHERE | PT_PLANE */
+    int32_t material; /* PT_DIFFUSE | PT_CHROME | PT_GLASS | PT_MEASURED */
+    double center[3];
+    double normal[3];
+    double radius;
+    double color[3];
+    double emission[3];
+    double ior;        /* Glass only */
+    double reflection; /* Glass only */
+    int32_t brdf_id;   /* PT_MEASURED only: table slot 0..PT_MAX_BRDF-1, else -1 */
+    int32_t reserved;
+} pt_body;
+
+/* Camera(origin, topleft, topright, bottomleft): main.cpp:144-152. */
+typedef struct pt_camera {
+    double origin[3];
+    double topleft[3];
+    double topright[3];
+    double bottomleft[3];
+} pt_camera;
+
+/* Scene (main.cpp:321-327) + what Renderer(Scene) needs. Copied at create time. */
+typedef struct pt_scene_desc {
+    int32_t width;
+    int32_t height;
+    pt_camera camera;
+    const pt_body* bodies;
+    int32_t body_count;
+    int32_t estimator; /* PT_EST_PT | PT_EST_NEE */
+    uint32_t flags;
+    uint32_t reserved;
+    uint64_t seed; /* replaces srand(time(NULL)) main.cpp:461 */
+} pt_scene_desc;
+
+typedef struct pt_scene pt_scene; /* opaque: Renderer + device state */
+
+#define PT_MAX_BRDF 8
+#define PT_BRDF_TABLE_DOUBLES (3 * 90 * 90 * 180) /* MatusikBRDF.h:24-26,102 */
+#define PT_MAX_DEPTH 5                            /* trace(): n > 4 returns, main.cpp:368 */
+
+/* Select the HIP device used by handles created afterwards on this thread (default 0). */
+int pt_set_device(int device);
+
+/* Replaces `Renderer(Scene)` (main.cpp:336-343; light list next_event.cpp:362-367). */
+int pt_scene_create(const pt_scene_desc* desc, pt_scene** out);
+int pt_scene_destroy(pt_scene* scene);
+
+/* Apply the Shape constructors to one body in place: a Plane stores normalize(normal)
+ * (main.cpp:176-179); a Sphere is unchanged.  pt_scene_create does this to its own copy. Host only. */
+int pt_body_construct(pt_body* body);
+
+/* The bodies as stored after construction (plane normals normalised). Returns the count. */
+int pt_scene_bodies(const pt_scene* scene, pt_body* out, int cap);
+
+/* Replaces MatusikBRDF::read_brdf (MatusikBRDF.h:84-108): upload one table (3*1458000 doubles,
+ * channel-planar R,G,B) into HBM, or read it from a file in the reference's format. */
+int pt_brdf_upload(pt_scene* scene, int brdf_id, const double* table, size_t n_doubles);
+int pt_brdf_load_file(pt_scene* scene, int brdf_id, const char* path);
+
+/* Multi-GPU sharding: this handle renders only the destination tiles (tile_w x tile_h pixels,
+ * numbered row-major) whose index % world == rank; other pixels of `accum` are left untouched.
+ * Default: rank 0 of 1.  The reference's counterpart is worker()'s per-thread split
+ * (main.cpp:436-458, 642-645). */
+int pt_set_partition(pt_scene* scene, int rank, int world, int tile_w, int tile_h);
+
+/* Replaces `for (i < iterations) renderer.iterate()` (main.cpp:439-442, 349-365): adds
+ * iterations [first_iteration, first_iteration + n_iterations) into accum (host memory).
+ * Samples of one pixel are added in iteration order, so the result does not depend on how a
+ * render is split into calls. */
+int pt_render(pt_scene* scene, int first_iteration, int n_iterations, double* accum_host);
+
+/* Same, with `accum_dev` in device memory and work queued on `stream` (a hipStream_t, or NULL).
+ * Returns without synchronising. */
+int pt_render_device(pt_scene* scene, int first_iteration, int n_iterations, double* accum_dev, void* stream);
+
+/* Nearest-hit scan (main.cpp:372-383) over a ray batch: rays6[n][6] = origin, direction.
+ * `skip` is a body index excluded from the scan (the light in next_event.cpp:415-419) or -1.
+ * idx[i] = -1 and t[i] = DBL_MAX on a miss.  Host pointers. */
+int pt_intersect_batch(pt_scene* scene, const double* rays6, int n, int skip, int32_t* idx, double* t);
+
+/* Shape::intersect of every body for every ray (main.cpp:181-191, 210-222): t_all[n][body_count]. */
+int pt_intersect_all(pt_scene* scene, const double* rays6, int n, double* t_all);
+
+/* Diagnostics for parity tests: trace n explicit samples (iteration, pixel index, x, y) and return
+ * radiance rgb[n][3], gather-path length nrec[n], bodies[n][5], offset points[n][5][3], a bit mask
+ * of lit vertices visible[n] (NEE) and the number of random draws used[n]. Any output may be NULL. */
+int pt_trace_paths(pt_scene* scene, const int32_t* it_idx2, const double* xy, int n, double* rgb, int32_t* nrec,
+                   int32_t* bodies, double* points, int32_t* visible, int32_t* used);
+
+/* Frame geometry of one iteration (main.cpp:352-357): ys[H], xs[H*W], row_len[H]; *nrows rows. */
+int pt_frame_layout(pt_scene* scene, int iteration, double* ys, double* xs, int32_t* row_len, int32_t* nrows);
+
+/* The random-number contract, evaluated on the device: n draws k (and u = k / 2147483647.0,
+ * main.cpp:19-22) of stream (seed, iteration, domain, index). */
+int pt_rng_fill(uint64_t seed, uint32_t iteration, uint32_t domain, uint32_t index, int n, int32_t* k, double* u);
+
+/* MatusikBRDF::lookup_brdf_val (MatusikBRDF.h:50-80) on an uploaded table: angles4[n][4] =
+ * theta_in, phi_in, theta_out, phi_out -> rgb[n][3], ind[n] (table index). */
+int pt_brdf_lookup(pt_scene* scene, int brdf_id, const double* angles4, int n, double* rgb, int32_t* ind);
+
+/* Replaces save() (main.cpp:408-434 / next_event.cpp:533-554): ASCII P3, byte-compatible. */
+int pt_save_ppm(const double* buffer, int samples, int width, int height, const char* path);
+
+/* The reference's hard-coded scenes as data: "nee15" (next_event.cpp:605-689), "main32"
+ * (main.cpp:473-607), "nee15_measured" (nee15 with bodies 0,1,6,7 measured, lit lights) and
+ * "synthetic10k" (nee15 room + 9985 extra spheres).  Fills desc (desc->bodies = bodies). */
+int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc, pt_body* bodies, int cap);
+
+/* Statistics of the last pt_render* call on this handle. */
+typedef struct pt_stats {
+    double paths;          /* (pixel, iteration) samples traced */
+    double kernel_ms;      /* device time of the estimator kernels (HIP events) */
+    double launches;       /* estimator kernel launches */
+} pt_stats;
+int pt_get_stats(const pt_scene* scene, pt_stats* out);
+
+const char* pt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

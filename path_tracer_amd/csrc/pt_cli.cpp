@@ -1,0 +1,111 @@
+// Drop-in executables for the reference's two programs:
+//   main        <width> <height> <iterations> <thread count>   (main.cpp:460-471, 642-656)
+//   next_event  <width> <height> <iterations> <thread count>   (next_event.cpp:587-598, 701-712)
+// Same positional arguments, same hard-coded scenes, same output file names and PPM bytes; the
+// per-pixel estimator runs on the GPU through the ptgpu C ABI.  Built twice from this file
+// (-DPT_PROG_NEE selects next_event).
+//
+// <thread count> keeps the reference's arithmetic: each of the T workers renders
+// iterations/T full frames into a private buffer and the buffers are summed (main.cpp:436-458);
+// here worker k renders iterations [k*n, (k+1)*n) and the sum runs in worker order.  save()
+// still divides by the requested total.
+//
+// Extra options, after the four positionals: --seed N (default: time, like srand(time(NULL))),
+// --gpu ID, --out PATH, --literal-height (next_event only: height = argv[1] as
+// next_event.cpp:596 literally does), --quiet.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../include/ptgpu.h"
+
+int main(int argc, const char* argv[]) {
+    if (argc < 5) {
+        printf("%s <width> <height> <iterations> <thread count>\n", argv[0]);
+        return 0;
+    }
+    int width = (int)strtol(argv[1], NULL, 10);
+    int height = (int)strtol(argv[2], NULL, 10);
+    int iterations = (int)strtol(argv[3], NULL, 10);
+    int thread_count = (int)strtol(argv[4], NULL, 10);
+    uint64_t seed = (uint64_t)time(NULL);
+    int gpu = 0;
+    bool quiet = false;
+    std::string out;
+    for (int i = 5; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], NULL, 10);
+        else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else if (a == "--quiet") quiet = true;
+#ifdef PT_PROG_NEE
+        else if (a == "--literal-height") height = width;
+#endif
+        else {
+            fprintf(stderr, "unknown option %s\n", a.c_str());
+            return 2;
+        }
+    }
+    if (thread_count < 1) thread_count = 1;
+#ifdef PT_PROG_NEE
+    const char* preset = "nee15";
+    int per_worker = iterations / thread_count;                          // next_event.cpp:703
+    if (out.empty()) out = "output.ppm";                                 // next_event.cpp:535
+#else
+    const char* preset = "main32";
+    int per_worker = (int)((double)iterations / (double)thread_count);   // main.cpp:644 (double -> int parameter)
+    if (out.empty()) out = "output_" + std::to_string(iterations) + ".ppm";  // main.cpp:411-412
+#endif
+    std::vector<pt_body> bodies(64);
+    pt_scene_desc desc;
+    if (pt_preset_scene(preset, width, height, &desc, bodies.data(), (int)bodies.size()) != PT_OK) {
+        fprintf(stderr, "cannot build scene\n");
+        return 1;
+    }
+    desc.seed = seed;
+    if (pt_set_device(gpu) != PT_OK) {
+        fprintf(stderr, "ptgpu: %s\n", pt_last_error());
+        return 1;
+    }
+    pt_scene* scene = NULL;
+    if (pt_scene_create(&desc, &scene) != PT_OK) {
+        fprintf(stderr, "ptgpu: %s\n", pt_last_error());
+        return 1;
+    }
+    size_t n = (size_t)width * height * 3;
+    std::vector<double> buffer(n, 0.0), priv;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < thread_count; ++k) {
+        double* dst = buffer.data();
+        if (thread_count > 1) {
+            priv.assign(n, 0.0);
+            dst = priv.data();
+        }
+        if (pt_render(scene, k * per_worker, per_worker, dst) != PT_OK) {
+            fprintf(stderr, "ptgpu: %s\n", pt_last_error());
+            return 1;
+        }
+        if (thread_count > 1)
+            for (size_t i = 0; i < n; ++i) buffer[i] += priv[i];
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!quiet) {
+        double paths = (double)width * height * (double)per_worker * thread_count;
+        fprintf(stderr, "ptgpu: %.0f paths in %.3f s = %.3e paths/s (seed %llu)\n", paths, secs, paths / secs,
+                (unsigned long long)seed);
+    }
+#ifndef PT_PROG_NEE
+    printf("saving to file \"%s\"\n", out.c_str());  // main.cpp:413
+#endif
+    int rc = pt_save_ppm(buffer.data(), iterations, width, height, out.c_str());
+    pt_scene_destroy(scene);
+    if (rc != PT_OK) {
+        fprintf(stderr, "cannot write %s\n", out.c_str());
+        return 1;
+    }
+    return 0;
+}

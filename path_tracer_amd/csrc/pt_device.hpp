@@ -1,0 +1,468 @@
+// Device-side building blocks of the estimator (gfx950, FP64 VALU, no FMA contraction).
+//
+// Every function states the reference lines it reproduces.  The reference is x86-64 g++ code:
+// IEEE double without fused multiply-add, evaluated left to right.  This translation unit must
+// be compiled with -ffp-contract=off; the only fused operations are explicit __builtin_fma calls
+// whose result is proven equal to the unfused reference expression.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+#define PTD_INLINE __device__ __forceinline__
+
+constexpr int kMaxDepth = 5;  // trace() returns at n > 4: main.cpp:368
+constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
+
+enum { kSphere = 0, kPlane = 1 };
+enum { kDiffuse = 0, kChrome = 1, kGlass = 2, kMeasured = 3 };
+enum { kEstPT = 0, kEstNEE = 1 };
+enum { kDomPixel = 0, kDomRow = 1, kDomFrame = 2, kDomSeq = 3 };
+
+// ---- V3: main.cpp:50-103 ---------------------------------------------------------------
+struct V3 {
+    double x, y, z;
+};
+PTD_INLINE V3 mk(double x, double y, double z) {
+    V3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+PTD_INLINE V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTD_INLINE V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTD_INLINE V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PTD_INLINE V3 muls(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+// dot: x*v.x + y*v.y + z*v.z, left to right (main.cpp:96-98)
+PTD_INLINE double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// normalize = divs(sqrt(dot)) = muls(1.0L / s) (main.cpp:92-102).  The reference forms the
+// reciprocal in x87 extended precision and then narrows it; a correctly rounded double
+// division gives the same double except when the 64-bit-mantissa quotient falls exactly on a
+// double midpoint (about 1 in 4096 reciprocals differs by one ulp).
+PTD_INLINE V3 normalize(V3 a) { return muls(a, 1.0 / sqrt(dot(a, a))); }
+
+// ---- random numbers --------------------------------------------------------------------
+// Stream contract: xoshiro128+ state seeded from (seed, iteration, domain, index) by three
+// splitmix64 finalisers; a draw is k = (s0 + s3) >> 1 in [0, 2^31-1] and
+// u = k / 2147483647.0, the mapping unifRand() applies to rand() (main.cpp:19-22).
+struct Rng {
+    uint32_t s0, s1, s2, s3;
+};
+
+PTD_INLINE uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+PTD_INLINE Rng rng_init(uint64_t seed, uint32_t iteration, uint32_t domain, uint32_t index) {
+    uint64_t a = mix64(seed + 0x9E3779B97F4A7C15ULL * ((((uint64_t)domain << 32) | iteration) + 1ULL));
+    uint64_t b = mix64(a ^ (0xD1B54A32D192ED03ULL * ((uint64_t)index + 1ULL)));
+    uint64_t c = mix64(b + 0x9E3779B97F4A7C15ULL);
+    Rng r;
+    r.s0 = (uint32_t)b;
+    r.s1 = (uint32_t)(b >> 32);
+    r.s2 = (uint32_t)c;
+    r.s3 = (uint32_t)(c >> 32);
+    if ((r.s0 | r.s1 | r.s2 | r.s3) == 0u) r.s0 = 0x9E3779B9u;
+    return r;
+}
+
+PTD_INLINE int32_t rng_next(Rng& r) {
+    uint32_t result = r.s0 + r.s3;
+    uint32_t t = r.s1 << 9;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = (r.s3 << 11) | (r.s3 >> 21);
+    return (int32_t)(result >> 1);
+}
+
+// rand() / double(RAND_MAX) with RAND_MAX = 2147483647: a correctly rounded division.
+PTD_INLINE double k_to_unit(int32_t k) { return (double)k / 2147483647.0; }
+
+struct Draws {
+    Rng rng;
+    int count;
+};
+PTD_INLINE double unif(Draws& d) {
+    d.count++;
+    return k_to_unit(rng_next(d.rng));
+}
+
+// ---- scene records ---------------------------------------------------------------------
+struct DGeom {  // 64 bytes, what the nearest-hit scan reads
+    double cx, cy, cz;
+    double nx, ny, nz;  // plane: stored (normalised) normal; sphere: nx = radius*radius
+    int32_t shape;
+    int32_t pad[3];
+};
+struct DMat {  // 96 bytes
+    double colr, colg, colb;
+    double emr, emg, emb;
+    double ior, refl;
+    int32_t material;
+    int32_t brdf_id;
+    int32_t pad[6];
+};
+
+struct DScene {
+    const DGeom* geom;
+    const DMat* mat;
+    const int32_t* lights;  // body indices with any emission channel >= 1 (next_event.cpp:362-367)
+    const double* brdf[8];
+    int32_t n_bodies;
+    int32_t n_lights;
+    int32_t width, height;
+    int32_t estimator;
+    uint32_t flags;
+    uint64_t seed;
+    // Camera (main.cpp:144-152): xd = topright - topleft, yd = bottomleft - topleft
+    double cam_o[3], cam_tl[3], cam_xd[3], cam_yd[3];
+};
+
+PTD_INLINE V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+
+// Camera::getPoint next_event.cpp:159-161: topleft.add(xd.muls(x)).add(yd.muls(y))
+PTD_INLINE V3 cam_point(const DScene& S, double x, double y) {
+    return add(add(ld3(S.cam_tl), muls(ld3(S.cam_xd), x)), muls(ld3(S.cam_yd), y));
+}
+
+// ---- intersection ----------------------------------------------------------------------
+// Plane::intersect main.cpp:181-191.  The reference compares against the long double literals
+// +-0.00001L; for a double operand that is the same as comparing with the double 0.00001
+// (the 53-bit round-up of 0.00001L equals the double literal).
+PTD_INLINE double intersect_plane(const DGeom& g, V3 o, V3 d) {
+    double n_dot_u = g.nx * d.x + g.ny * d.y + g.nz * d.z;
+    double n_dot_p0 = g.nx * (g.cx - o.x) + g.ny * (g.cy - o.y) + g.nz * (g.cz - o.z);
+    double t = n_dot_p0 / n_dot_u;
+    return ((n_dot_u > -0.00001) && (n_dot_u < 0.00001)) ? -1.0 : t;
+}
+
+// Sphere::intersect main.cpp:210-222 (near root only, assumes |d| = 1).
+PTD_INLINE double intersect_sphere(const DGeom& g, V3 o, V3 d) {
+    double dx = o.x - g.cx, dy = o.y - g.cy, dz = o.z - g.cz;
+    double b = dx * d.x + dy * d.y + dz * d.z;
+    double c = (dx * dx + dy * dy + dz * dz) - g.nx;
+    double disc = (b * b) - c;
+    double t = -1.0;
+    if (disc > 0.0) t = -b - sqrt(disc);
+    return t;
+}
+
+PTD_INLINE double intersect_body(const DGeom& g, V3 o, V3 d) {
+    return g.shape == kPlane ? intersect_plane(g, o, d) : intersect_sphere(g, o, d);
+}
+
+// Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint), ties to the larger index;
+// `skip` is the light excluded by next_event.cpp:415-419 (-1: none).  Body records are read at
+// wave-uniform addresses.
+PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, double& tmin) {
+    int hit = -1;
+    double mint = 1.7976931348623157e308;  // DBL_MAX
+    for (int i = 0; i < n; ++i) {
+        DGeom g = geom[i];
+        double t = intersect_body(g, o, d);
+        bool take = (t > 0.0) && (t <= mint) && (i != skip);
+        mint = take ? t : mint;
+        hit = take ? i : hit;
+    }
+    tmin = mint;
+    return hit;
+}
+
+// ---- materials -------------------------------------------------------------------------
+// getRandomNormalInHemisphere main.cpp:105-117.  Draw order z, y, x (g++ evaluates the
+// constructor arguments right to left); the normalised copy is discarded by the reference.
+PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
+    V3 v;
+    do {
+        v.z = unif(dr) * 2.0 - 1.0;
+        v.y = unif(dr) * 2.0 - 1.0;
+        v.x = unif(dr) * 2.0 - 1.0;
+    } while (dot(v, v) > 1.0);
+    if (dot(v, n) < 0.0) v = muls(v, -1.0);
+    return v;
+}
+
+// Chrome::bounce main.cpp:261-265
+PTD_INLINE V3 bounce_chrome(V3 d, V3 n) {
+    double theta1 = fabs(dot(d, n));
+    return add(d, muls(n, theta1 * 2.0));
+}
+
+// Glass::bounce main.cpp:279-305.  theta1 = fabs(..) >= 0 always, so internal = ior,
+// external = 1.  (The reference evaluates theta2 in x87 extended precision; here it is double.)
+PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double refl) {
+    double theta1 = fabs(dot(d, n));
+    double internalIndex = ior, externalIndex = 1.0;
+    if (!(theta1 >= 0.0)) {  // NaN only
+        internalIndex = 1.0;
+        externalIndex = ior;
+    }
+    double eta = externalIndex / internalIndex;
+    double theta2 = sqrt(1.0 - (eta * eta) * (1.0 - (theta1 * theta1)));
+    double rs = (externalIndex * theta1 - internalIndex * theta2) / (externalIndex * theta1 + internalIndex * theta2);
+    double rp = (internalIndex * theta1 - externalIndex * theta2) / (internalIndex * theta1 + externalIndex * theta2);
+    double reflectance = (rs * rs + rp * rp);
+    if (unif(dr) < reflectance + refl) return add(d, muls(n, theta1 * 2.0));
+    return add(muls(add(d, muls(n, theta1)), eta), muls(n, -theta2));
+}
+
+PTD_INLINE V3 bounce(const DMat& m, Draws& dr, V3 d, V3 n) {
+    if (m.material == kChrome) return bounce_chrome(d, n);
+    if (m.material == kGlass) return bounce_glass(dr, d, n, m.ior, m.refl);
+    return random_in_hemisphere(dr, n);  // Material::bounce main.cpp:250-253
+}
+
+// getNormal: Plane main.cpp:192-194, Sphere main.cpp:224-226
+PTD_INLINE V3 shape_normal(const DGeom& g, V3 point) {
+    if (g.shape == kPlane) return mk(g.nx, g.ny, g.nz);
+    return normalize(sub(point, mk(g.cx, g.cy, g.cz)));
+}
+
+// mint*1.0000001L and mint*0.9999999L (main.cpp:396,400): the literals have 64-bit
+// significands; each is split into two doubles (hi + lo exactly) and the product is rounded
+// once, which reproduces the narrowed x87 product up to double-rounding ties.
+PTD_INLINE double mul_ext(double t, double chi, double clo) {
+    double p = t * chi;
+    double e1 = __builtin_fma(t, chi, -p);  // exact error of the product
+    double e2 = t * clo;
+    return p + (e1 + e2);
+}
+PTD_INLINE double mul_1p0000001(double t) { return mul_ext(t, 0x1.000001ad7f29bp+0, -0x1.0d8p-54); }
+PTD_INLINE double mul_0p9999999(double t) { return mul_ext(t, 0x1.fffffca501acbp-1, -0x1.e58p-55); }
+
+// ---- measured BRDF: MatusikBRDF.h ------------------------------------------------------
+PTD_INLINE void brdf_normalize(double* v) {  // :124-130
+    double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] = v[0] / len;
+    v[1] = v[1] / len;
+    v[2] = v[2] / len;
+}
+
+PTD_INLINE void brdf_rotate(const double* vector, const double* axis, double angle, double* out) {  // :133-156
+    double cos_ang = cos(angle);
+    double sin_ang = sin(angle);
+    out[0] = vector[0] * cos_ang;
+    out[1] = vector[1] * cos_ang;
+    out[2] = vector[2] * cos_ang;
+    double temp = axis[0] * vector[0] + axis[1] * vector[1] + axis[2] * vector[2];
+    temp = temp * (1.0 - cos_ang);
+    out[0] += axis[0] * temp;
+    out[1] += axis[1] * temp;
+    out[2] += axis[2] * temp;
+    double cx = axis[1] * vector[2] - axis[2] * vector[1];
+    double cy = axis[2] * vector[0] - axis[0] * vector[2];
+    double cz = axis[0] * vector[1] - axis[1] * vector[0];
+    out[0] += cx * sin_ang;
+    out[1] += cy * sin_ang;
+    out[2] += cz * sin_ang;
+}
+
+// double -> int as the x86 reference does it: NaN and out-of-range give INT_MIN.
+PTD_INLINE int to_int_x86(double v) {
+    if (!(v == v) || v >= 2147483648.0 || v <= -2147483649.0) return (int)0x80000000;
+    return (int)v;
+}
+
+constexpr double kPi = 0x1.921fb54442d18p+1;       // M_PI
+constexpr double kHalfPi = 0x1.921fb54442d18p+0;   // M_PI / 2.0 == M_PI * 0.5
+
+PTD_INLINE int theta_half_index(double theta_half) {  // :211-223
+    if (theta_half <= 0.0) return 0;
+    double theta_half_deg = ((theta_half / kHalfPi) * 90);
+    double temp = theta_half_deg * 90;
+    temp = sqrt(temp);
+    int ret_val = to_int_x86(temp);
+    if (ret_val < 0) ret_val = 0;
+    if (ret_val >= 90) ret_val = 89;
+    return ret_val;
+}
+PTD_INLINE int theta_diff_index(double theta_diff) {  // :228-237
+    int tmp = to_int_x86(theta_diff / kHalfPi * 90);
+    if (tmp < 0) return 0;
+    if (tmp < 89) return tmp;
+    return 89;
+}
+PTD_INLINE int phi_diff_index(double phi_diff) {  // :241-257
+    if (phi_diff < 0.0) phi_diff += kPi;
+    int tmp = to_int_x86(phi_diff / kPi * 360 / 2);
+    if (tmp < 0) return 0;
+    if (tmp < 179) return tmp;
+    return 179;
+}
+
+// std_coords_to_half_diff_coords :159-205 and the index of lookup_brdf_val :63-66
+PTD_INLINE int brdf_index(double theta_in, double fi_in, double theta_out, double fi_out) {
+    double in_vec_z = cos(theta_in);
+    double proj_in_vec = sin(theta_in);
+    double in_vec_x = proj_in_vec * cos(fi_in);
+    double in_vec_y = proj_in_vec * sin(fi_in);
+    double in[3] = {in_vec_x, in_vec_y, in_vec_z};
+    brdf_normalize(in);
+    double out_vec_z = cos(theta_out);
+    double proj_out_vec = sin(theta_out);
+    double out_vec_x = proj_out_vec * cos(fi_out);
+    double out_vec_y = proj_out_vec * sin(fi_out);
+    // the reference also normalises `out`, but only in_vec_*/out_vec_* and `in` are used afterwards
+    double half[3] = {(in_vec_x + out_vec_x) / 2.0, (in_vec_y + out_vec_y) / 2.0, (in_vec_z + out_vec_z) / 2.0};
+    brdf_normalize(half);
+    double theta_half = acos(half[2]);
+    double fi_half = atan2(half[1], half[0]);
+    const double bi_normal[3] = {0.0, 1.0, 0.0};
+    const double normal[3] = {0.0, 0.0, 1.0};
+    double temp[3], diff[3];
+    brdf_rotate(in, normal, -fi_half, temp);
+    brdf_rotate(temp, bi_normal, -theta_half, diff);
+    double theta_diff = acos(diff[2]);
+    double fi_diff = atan2(diff[1], diff[0]);
+    return phi_diff_index(fi_diff) + theta_diff_index(theta_diff) * 360 / 2 + theta_half_index(theta_half) * 360 / 2 * 90;
+}
+
+// lookup_brdf_val :50-80.  Three 8-byte gathers at strides of 11.66 MB from an HBM-resident table.
+PTD_INLINE V3 brdf_lookup(const double* __restrict__ table, double theta_in, double fi_in, double theta_out,
+                          double fi_out, int* ind_out) {
+    int ind = brdf_index(theta_in, fi_in, theta_out, fi_out);
+    if (ind_out) *ind_out = ind;
+    double r = table[ind] * (1.0 / 1500.0);
+    double g = table[ind + kBrdfN] * (1.15 / 1500.0);
+    double b = table[ind + 2 * kBrdfN] * (1.66 / 1500.0);
+    if (r < 0.0 || g < 0.0 || b < 0.0) r = g = b = 0.0;
+    return mk(r, g, b);
+}
+
+// vector_to_spherical raytrace3.cpp:725-728 (pow(x, 2) is x*x)
+PTD_INLINE void vector_to_spherical(V3 in, double& theta, double& phi) {
+    theta = atan(in.y / in.x);
+    phi = acos(in.z / sqrt(in.x * in.x + in.y * in.y + in.z * in.z));
+}
+
+// ---- the estimator ---------------------------------------------------------------------
+// Gather-path records live in LDS: point component c of vertex k of thread tid is at
+// pts[(k*3 + c) * stride + tid], its body at bod[k * stride + tid].
+struct Records {
+    double* pts;
+    int32_t* bod;
+    int stride;
+    int tid;
+    PTD_INLINE void put(int k, V3 p, int body) const {
+        pts[(k * 3 + 0) * stride + tid] = p.x;
+        pts[(k * 3 + 1) * stride + tid] = p.y;
+        pts[(k * 3 + 2) * stride + tid] = p.z;
+        bod[k * stride + tid] = body;
+    }
+    PTD_INLINE V3 point(int k) const {
+        return mk(pts[(k * 3 + 0) * stride + tid], pts[(k * 3 + 1) * stride + tid], pts[(k * 3 + 2) * stride + tid]);
+    }
+    PTD_INLINE int body(int k) const { return bod[k * stride + tid]; }
+};
+
+struct PathResult {
+    V3 rgb;
+    int nrec;
+    int visible;
+};
+
+// One (pixel, iteration) sample.
+//  PT : Renderer::trace main.cpp:367-405 — the recursion `trace(next)*color + emission` is a Horner
+//       evaluation from the deepest hit outwards.
+//  NEE: pixel body of Renderer::iterate next_event.cpp:384-470 with trace() next_event.cpp:491-530.
+template <int EST, bool MEASURED>
+PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y, const Records& rec) {
+    const DGeom* __restrict__ geom = S.geom;
+    const DMat* __restrict__ mat = S.mat;
+    V3 o = ld3(S.cam_o);
+    V3 campt = cam_point(S, x, y);
+    V3 d = normalize(sub(campt, o));  // Camera::getRay main.cpp:154-157
+    int n = 0;
+#pragma unroll 1
+    for (; n < kMaxDepth; ++n) {
+        double mint;
+        int hit = nearest_hit(geom, S.n_bodies, o, d, -1, mint);
+        if (hit < 0) break;
+        DGeom g = geom[hit];
+        DMat m = mat[hit];
+        V3 point = add(o, muls(d, mint));
+        V3 normal = shape_normal(g, point);
+        V3 dir = bounce(m, dr, d, normal);
+        // main.cpp:394-401 (the comparison is against the float 0.0f)
+        double tt = (dot(dir, d) > 0.0) ? mul_1p0000001(mint) : mul_0p9999999(mint);
+        point = add(o, muls(d, tt));
+        rec.put(n, point, hit);
+        o = point;
+        d = dir;
+    }
+    PathResult R;
+    R.nrec = n;
+    R.visible = 0;
+    V3 L = mk(0.0, 0.0, 0.0);
+    if (EST == kEstPT) {
+#pragma unroll 1
+        for (int k = n - 1; k >= 0; --k) {
+            DMat m = mat[rec.body(k)];
+            L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+        }
+        R.rgb = L;
+        return R;
+    }
+    // lights[unifRand(lights.size() - 1)] next_event.cpp:390; unifRand(long) main.cpp:36-47
+    int li = 0;
+    {
+        int nl = S.n_lights - 1;
+        if (nl < 0) nl = -nl;
+        if (nl != 0) {
+            long guard = (long)(unif(dr) * (double)nl) + 1;
+            li = guard > nl ? nl : (int)guard;
+        }
+    }
+    int light = S.lights[li];
+    DMat lm = mat[light];
+    // light->shape->center through a Shape* is the never-assigned base member (0,0,0)
+    // (next_event.cpp:167,406-407) unless the scene asks for the real centre.
+    V3 lc = mk(0.0, 0.0, 0.0);
+    if (S.flags & 1u) {
+        DGeom lg = geom[light];
+        lc = mk(lg.cx, lg.cy, lg.cz);
+    }
+    V3 lterm = mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
+#pragma unroll 1
+    for (int gi = n - 1; gi >= 0; --gi) {
+        V3 P = rec.point(gi);
+        int target = rec.body(gi);
+        V3 bd = normalize(sub(P, lc));
+        double mint;
+        int hit = nearest_hit(geom, S.n_bodies, lc, bd, light, mint);
+        if (hit != target) continue;
+        R.visible |= 1 << gi;
+        DGeom g = geom[hit];
+        DMat m = mat[hit];
+        V3 next_point = campt;
+        if (gi >= 1) next_point = rec.point(gi - 1);
+        V3 nprime = normalize(sub(next_point, P));
+        V3 scale;
+        if (MEASURED && m.material == kMeasured) {
+            // Defined by this build: the table RGB replaces the scalar flux (the reference's own
+            // lookups, raytrace3.cpp:646-676, are never executed).
+            double ti, pi, to, po;
+            vector_to_spherical(bd, ti, pi);
+            vector_to_spherical(nprime, to, po);
+            V3 f = brdf_lookup(S.brdf[m.brdf_id], ti, pi, to, po, nullptr);
+            scale = mul(lterm, f);
+        } else {
+            V3 light_brdf = bounce(m, dr, bd, nprime);
+            double light_flux = fabs(dot(light_brdf, shape_normal(g, P)));
+            scale = muls(lterm, light_flux);
+        }
+        // next_event.cpp:462-463
+        L = add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+    }
+    R.rgb = L;
+    return R;
+}
+
+}  // namespace ptd

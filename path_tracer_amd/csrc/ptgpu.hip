@@ -1,0 +1,779 @@
+// ptgpu — kernels and C ABI (see include/ptgpu.h).  gfx950 only.
+//
+// Render pipeline for one batch of B iterations:
+//   k_frame_layout : per iteration, the jitter tables of Renderer::iterate (main.cpp:352-357):
+//                    y per row, x per pixel (running sums, exactly as the reference's loops
+//                    accumulate them), row lengths and the running-index row starts.
+//   k_trace<EST>   : one thread per (destination pixel, iteration): camera ray, <=5 segments of
+//                    nearest-hit scan + bounce, then (NEE) light pick, <=5 shadow scans and the
+//                    backward colour recurrence.  Writes one FP64 RGB sample.
+//   k_accumulate   : per destination pixel, adds the batch's samples in iteration order into
+//                    the caller's FP64 buffer (single writer, no atomics, deterministic).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptgpu.h"
+#include "pt_device.hpp"
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_device = 0;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+constexpr int kBlock = 256;
+
+struct Partition {
+    int rank, world;
+    int tile_w, tile_h;
+    int tiles_x, tiles_y;
+    int owned_tiles;
+};
+
+// Destination slot of thread `tid` in owned tile `q`, or -1 outside the image.
+PTD_INLINE int slot_of(const Partition& P, int q, int tid, int W, int H) {
+    int tile = q * P.world + P.rank;
+    int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    int px = tx * P.tile_w + tid % P.tile_w;
+    int py = ty * P.tile_h + tid / P.tile_w;
+    if (px >= W || py >= H) return -1;
+    return py * W + px;
+}
+
+// ---- k_frame_layout ----------------------------------------------------------------------
+// One block per iteration.  Each thread owns a contiguous chunk of rows: it runs their x chains
+// (x0 = u/W, then x += xstep while x < 0.99999L, main.cpp:355-357), thread 0 also runs the y
+// chain (main.cpp:352-354); a block scan turns row lengths into running-index row starts.
+// xstep/ystep are the doubles the reference initialises from 1.0L/(double)W and 1.0L/(double)H.
+__global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int H, int first_it, double xstep,
+                                                       double ystep, double* __restrict__ xs, double* __restrict__ ys,
+                                                       int32_t* __restrict__ row_start, int32_t* __restrict__ npix) {
+    __shared__ int s_part[1024];
+    __shared__ int s_nrows;
+    const int b = blockIdx.x;
+    const uint32_t it = (uint32_t)(first_it + b);
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int chunk = (H + nthr - 1) / nthr;
+    const int r0 = tid * chunk;
+    const int r1 = min(H, r0 + chunk);
+    double* xs_b = xs + (size_t)b * H * W;
+    double* ys_b = ys + (size_t)b * H;
+    int32_t* rs_b = row_start + (size_t)b * (H + 1);
+
+    if (tid == 0) {
+        Rng j = rng_init(seed, it, kDomFrame, 0);
+        double y = k_to_unit(rng_next(j)) / (double)H;
+        int r = 0;
+        while (y < 0.99999 && r < H) {
+            ys_b[r] = y;
+            r++;
+            y += ystep;
+        }
+        s_nrows = r;
+    }
+    __syncthreads();
+    const int nrows = s_nrows;
+    int local = 0;
+    for (int r = r0; r < r1; ++r) {
+        int len = 0;
+        if (r < nrows) {
+            Rng j = rng_init(seed, it, kDomRow, (uint32_t)r);
+            double x = k_to_unit(rng_next(j)) / (double)W;
+            double* row = xs_b + (size_t)r * W;
+            while (x < 0.99999 && len < W) {
+                row[len] = x;
+                len++;
+                x += xstep;
+            }
+        }
+        rs_b[r + 1] = len;  // temporarily the row length
+        local += len;
+    }
+    s_part[tid] = local;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over the per-thread totals
+    for (int off = 1; off < nthr; off <<= 1) {
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - local;  // exclusive prefix
+    for (int r = r0; r < r1; ++r) {
+        int len = rs_b[r + 1];
+        if (r == 0) rs_b[0] = 0;
+        run += len;
+        rs_b[r + 1] = run;
+    }
+    if (tid == nthr - 1) npix[b] = s_part[tid];
+}
+
+// ---- k_trace -----------------------------------------------------------------------------
+template <int EST, bool MEASURED>
+__global__ void __launch_bounds__(kBlock) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+                                                  const double* __restrict__ ys, const int32_t* __restrict__ row_start,
+                                                  const int32_t* __restrict__ npix, double* __restrict__ samples,
+                                                  size_t sample_stride) {
+    __shared__ double s_pts[kMaxDepth * 3 * kBlock];
+    __shared__ int32_t s_bod[kMaxDepth * kBlock];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int W = S.width, H = S.height;
+    const int slot = slot_of(P, blockIdx.x, tid, W, H);
+    const size_t j = (size_t)blockIdx.x * kBlock + tid;
+    double* out = samples + (size_t)b * 3 * sample_stride + j;
+    V3 rgb = mk(0.0, 0.0, 0.0);
+    if (slot >= 0 && slot < npix[b]) {
+        const int32_t* rs = row_start + (size_t)b * (H + 1);
+        int r = slot / W;
+        while (slot >= rs[r + 1]) r++;
+        int c = slot - rs[r];
+        double x = xs[((size_t)b * H + r) * W + c];
+        double y = ys[(size_t)b * H + r];
+        Draws dr;
+        dr.rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
+        dr.count = 0;
+        Records rec;
+        rec.pts = s_pts;
+        rec.bod = s_bod;
+        rec.stride = kBlock;
+        rec.tid = tid;
+        PathResult R = trace_path<EST, MEASURED>(S, dr, x, y, rec);
+        rgb = R.rgb;
+    }
+    out[0] = rgb.x;
+    out[sample_stride] = rgb.y;
+    out[2 * sample_stride] = rgb.z;
+}
+
+// ---- k_accumulate ------------------------------------------------------------------------
+// buffer[i] += sample for every iteration whose frame reaches running index i
+// (main.cpp:362), in iteration order.
+__global__ void __launch_bounds__(kBlock) k_accumulate(Partition P, int W, int H, int B,
+                                                       const int32_t* __restrict__ npix,
+                                                       const double* __restrict__ samples, size_t sample_stride,
+                                                       double* __restrict__ accum) {
+    const int tid = threadIdx.x;
+    const int slot = slot_of(P, blockIdx.x, tid, W, H);
+    if (slot < 0) return;
+    const size_t j = (size_t)blockIdx.x * kBlock + tid;
+    double* a = accum + (size_t)slot * 3;
+    double ax = a[0], ay = a[1], az = a[2];
+    for (int b = 0; b < B; ++b) {
+        if (slot < npix[b]) {
+            const double* s = samples + (size_t)b * 3 * sample_stride + j;
+            ax += s[0];
+            ay += s[sample_stride];
+            az += s[2 * sample_stride];
+        }
+    }
+    a[0] = ax;
+    a[1] = ay;
+    a[2] = az;
+}
+
+// ---- test / diagnostic kernels ---------------------------------------------------------------
+__global__ void k_intersect_batch(DScene S, const double* __restrict__ rays6, int n, int skip,
+                                  int32_t* __restrict__ idx, double* __restrict__ t) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = ld3(rays6 + 6 * (size_t)i), d = ld3(rays6 + 6 * (size_t)i + 3);
+    double mint;
+    int hit = nearest_hit(S.geom, S.n_bodies, o, d, skip, mint);
+    idx[i] = hit;
+    t[i] = mint;
+}
+
+__global__ void k_intersect_all(DScene S, const double* __restrict__ rays6, int n, double* __restrict__ t_all) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = ld3(rays6 + 6 * (size_t)i), d = ld3(rays6 + 6 * (size_t)i + 3);
+    for (int b = 0; b < S.n_bodies; ++b) t_all[(size_t)i * S.n_bodies + b] = intersect_body(S.geom[b], o, d);
+}
+
+template <int EST, bool MEASURED>
+__global__ void __launch_bounds__(kBlock) k_trace_paths(DScene S, const int32_t* __restrict__ it_idx2,
+                                                        const double* __restrict__ xy, int n, double* rgb,
+                                                        int32_t* nrec, int32_t* bodies, double* points,
+                                                        int32_t* visible, int32_t* used) {
+    __shared__ double s_pts[kMaxDepth * 3 * kBlock];
+    __shared__ int32_t s_bod[kMaxDepth * kBlock];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Draws dr;
+    dr.rng = rng_init(S.seed, (uint32_t)it_idx2[2 * i], kDomPixel, (uint32_t)it_idx2[2 * i + 1]);
+    dr.count = 0;
+    Records rec;
+    rec.pts = s_pts;
+    rec.bod = s_bod;
+    rec.stride = kBlock;
+    rec.tid = threadIdx.x;
+    PathResult R = trace_path<EST, MEASURED>(S, dr, xy[2 * i], xy[2 * i + 1], rec);
+    if (rgb) {
+        rgb[3 * i] = R.rgb.x;
+        rgb[3 * i + 1] = R.rgb.y;
+        rgb[3 * i + 2] = R.rgb.z;
+    }
+    if (nrec) nrec[i] = R.nrec;
+    for (int k = 0; k < kMaxDepth; ++k) {
+        bool have = k < R.nrec;
+        V3 p = have ? rec.point(k) : mk(0.0, 0.0, 0.0);
+        if (bodies) bodies[5 * i + k] = have ? rec.body(k) : -1;
+        if (points) {
+            points[15 * i + 3 * k] = p.x;
+            points[15 * i + 3 * k + 1] = p.y;
+            points[15 * i + 3 * k + 2] = p.z;
+        }
+    }
+    if (visible) visible[i] = R.visible;
+    if (used) used[i] = dr.count;
+}
+
+__global__ void k_rng_fill(uint64_t seed, uint32_t it, uint32_t dom, uint32_t idx, int n, int32_t* k, double* u) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng r = rng_init(seed, it, dom, idx);
+    for (int i = 0; i < n; ++i) {
+        int32_t v = rng_next(r);
+        k[i] = v;
+        u[i] = k_to_unit(v);
+    }
+}
+
+__global__ void k_brdf_lookup(const double* __restrict__ table, const double* __restrict__ angles4, int n,
+                              double* __restrict__ rgb, int32_t* __restrict__ ind) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* a = angles4 + 4 * (size_t)i;
+    int id;
+    V3 f = brdf_lookup(table, a[0], a[1], a[2], a[3], &id);
+    rgb[3 * i] = f.x;
+    rgb[3 * i + 1] = f.y;
+    rgb[3 * i + 2] = f.z;
+    ind[i] = id;
+}
+
+// ---- host state ------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return PT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return fail(PT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        bytes = need;
+        return PT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct pt_scene {
+    int device = 0;
+    int width = 0, height = 0, estimator = 0;
+    uint32_t flags = 0;
+    uint64_t seed = 0;
+    pt_camera camera;
+    std::vector<pt_body> bodies;  // as stored (normals normalised)
+    std::vector<int32_t> lights;
+    Partition part;
+    DScene ds;
+    DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
+    DevBuf d_xs, d_ys, d_rowstart, d_npix, d_samples, d_accum;
+    double xstep = 0, ystep = 0;
+    int batch = 1;
+    std::vector<hipEvent_t> ev;  // start/stop pairs of the estimator launches of the last render
+    size_t ev_used = 0;
+    double last_paths = 0;
+    bool has_measured = false;  // any PT_MEASURED body: selects the kernel variant with the table lookup
+};
+
+namespace {
+
+int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
+    if (world < 1 || rank < 0 || rank >= world) return fail(PT_ERR_INVALID, "partition: rank/world out of range");
+    if (tw < 1 || th < 1 || tw * th != kBlock) return fail(PT_ERR_INVALID, "partition: tile_w*tile_h must be 256");
+    Partition& P = s->part;
+    P.rank = rank;
+    P.world = world;
+    P.tile_w = tw;
+    P.tile_h = th;
+    P.tiles_x = (s->width + tw - 1) / tw;
+    P.tiles_y = (s->height + th - 1) / th;
+    int total = P.tiles_x * P.tiles_y;
+    P.owned_tiles = total > rank ? (total - rank + world - 1) / world : 0;
+    // batch: about 2^24 paths per launch, at most 64 iterations
+    size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
+    size_t b = ((size_t)1 << 24) / per_it;
+    s->batch = (int)std::min<size_t>(64, std::max<size_t>(1, b));
+    return PT_OK;
+}
+
+int ensure_render_buffers(pt_scene* s) {
+    const size_t W = s->width, H = s->height, B = s->batch;
+    int rc;
+    if ((rc = s->d_xs.ensure(B * H * W * sizeof(double)))) return rc;
+    if ((rc = s->d_ys.ensure(B * H * sizeof(double)))) return rc;
+    if ((rc = s->d_rowstart.ensure(B * (H + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = s->d_npix.ensure(B * sizeof(int32_t)))) return rc;
+    size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
+    if ((rc = s->d_samples.ensure(B * 3 * J * sizeof(double)))) return rc;
+    return PT_OK;
+}
+
+int upload_scene(pt_scene* s) {
+    const int n = (int)s->bodies.size();
+    std::vector<DGeom> geom(n);
+    std::vector<DMat> mat(n);
+    for (int i = 0; i < n; ++i) {
+        const pt_body& b = s->bodies[i];
+        DGeom g;
+        memset(&g, 0, sizeof g);
+        g.cx = b.center[0];
+        g.cy = b.center[1];
+        g.cz = b.center[2];
+        g.shape = b.shape;
+        if (b.shape == PT_PLANE) {
+            g.nx = b.normal[0];
+            g.ny = b.normal[1];
+            g.nz = b.normal[2];
+        } else {
+            g.nx = b.radius * b.radius;  // Sphere ctor radius2 main.cpp:207
+        }
+        geom[i] = g;
+        DMat m;
+        memset(&m, 0, sizeof m);
+        m.colr = b.color[0];
+        m.colg = b.color[1];
+        m.colb = b.color[2];
+        m.emr = b.emission[0];
+        m.emg = b.emission[1];
+        m.emb = b.emission[2];
+        m.ior = b.ior;
+        m.refl = b.reflection;
+        m.material = b.material;
+        m.brdf_id = b.brdf_id;
+        mat[i] = m;
+    }
+    int rc;
+    if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
+    if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
+    if ((rc = s->d_lights.ensure(sizeof(int32_t) * std::max<size_t>(1, s->lights.size())))) return rc;
+    HIP_TRY(hipMemcpy(s->d_geom.p, geom.data(), sizeof(DGeom) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_mat.p, mat.data(), sizeof(DMat) * n, hipMemcpyHostToDevice));
+    if (!s->lights.empty())
+        HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), sizeof(int32_t) * s->lights.size(), hipMemcpyHostToDevice));
+    DScene& D = s->ds;
+    memset(&D, 0, sizeof D);
+    D.geom = (const DGeom*)s->d_geom.p;
+    D.mat = (const DMat*)s->d_mat.p;
+    D.lights = (const int32_t*)s->d_lights.p;
+    D.n_bodies = n;
+    D.n_lights = (int)s->lights.size();
+    D.width = s->width;
+    D.height = s->height;
+    D.estimator = s->estimator;
+    D.flags = s->flags;
+    D.seed = s->seed;
+    for (int k = 0; k < 3; ++k) {
+        D.cam_o[k] = s->camera.origin[k];
+        D.cam_tl[k] = s->camera.topleft[k];
+        D.cam_xd[k] = s->camera.topright[k] - s->camera.topleft[k];
+        D.cam_yd[k] = s->camera.bottomleft[k] - s->camera.topleft[k];
+    }
+    return PT_OK;
+}
+
+int check_measured_tables(const pt_scene* s) {
+    for (const pt_body& b : s->bodies)
+        if (b.material == PT_MEASURED) {
+            if (b.brdf_id < 0 || b.brdf_id >= PT_MAX_BRDF) return fail(PT_ERR_INVALID, "measured body: brdf_id out of range");
+            if (!s->d_brdf[b.brdf_id].p) return fail(PT_ERR_INVALID, "measured body: BRDF table not uploaded");
+        }
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+
+int pt_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return PT_OK;
+}
+
+int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
+    if (!desc || !out) return fail(PT_ERR_INVALID, "pt_scene_create: null argument");
+    if (desc->width < 1 || desc->height < 1) return fail(PT_ERR_INVALID, "pt_scene_create: width/height must be >= 1");
+    if ((int64_t)desc->width * desc->height > (int64_t)1 << 28) return fail(PT_ERR_INVALID, "pt_scene_create: frame too large");
+    if (desc->body_count < 1 || !desc->bodies) return fail(PT_ERR_INVALID, "pt_scene_create: no bodies");
+    if (desc->estimator != PT_EST_PT && desc->estimator != PT_EST_NEE) return fail(PT_ERR_INVALID, "pt_scene_create: estimator");
+    pt_scene* s = new (std::nothrow) pt_scene();
+    if (!s) return fail(PT_ERR_NOMEM, "pt_scene_create: out of host memory");
+    s->device = g_device;
+    hipError_t e = hipSetDevice(s->device);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(PT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
+    s->width = desc->width;
+    s->height = desc->height;
+    s->estimator = desc->estimator;
+    s->flags = desc->flags;
+    s->seed = desc->seed;
+    s->camera = desc->camera;
+    s->bodies.assign(desc->bodies, desc->bodies + desc->body_count);
+    for (size_t i = 0; i < s->bodies.size(); ++i) {
+        pt_body& b = s->bodies[i];
+        if (b.shape != PT_SPHERE && b.shape != PT_PLANE) {
+            delete s;
+            return fail(PT_ERR_INVALID, "pt_scene_create: unknown shape");
+        }
+        if (b.material < PT_DIFFUSE || b.material > PT_MEASURED) {
+            delete s;
+            return fail(PT_ERR_INVALID, "pt_scene_create: unknown material");
+        }
+        pt_body_construct(&b);
+        if (b.material == PT_MEASURED) s->has_measured = true;
+        // Renderer ctor light list next_event.cpp:362-367
+        if (b.emission[0] >= 1.0 || b.emission[1] >= 1.0 || b.emission[2] >= 1.0) s->lights.push_back((int32_t)i);
+    }
+    if (s->estimator == PT_EST_NEE && s->lights.empty()) {
+        delete s;
+        return fail(PT_ERR_INVALID, "pt_scene_create: next-event estimation needs a body with emission >= 1");
+    }
+    // Loop steps of Renderer::iterate: double xstep = 1.0L / (double)width (main.cpp:352,355)
+    s->xstep = (double)(1.0L / (long double)(double)s->width);
+    s->ystep = (double)(1.0L / (long double)(double)s->height);
+    int rc = setup_partition(s, 0, 1, 32, 8);
+    if (rc == PT_OK) rc = upload_scene(s);
+    if (rc != PT_OK) {
+        pt_scene_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return PT_OK;
+}
+
+int pt_scene_destroy(pt_scene* s) {
+    if (!s) return PT_OK;
+    (void)hipSetDevice(s->device);
+    s->d_geom.release();
+    s->d_mat.release();
+    s->d_lights.release();
+    for (auto& b : s->d_brdf) b.release();
+    s->d_xs.release();
+    s->d_ys.release();
+    s->d_rowstart.release();
+    s->d_npix.release();
+    s->d_samples.release();
+    s->d_accum.release();
+    for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    delete s;
+    return PT_OK;
+}
+
+int pt_scene_bodies(const pt_scene* s, pt_body* out, int cap) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    int n = (int)s->bodies.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = s->bodies[i];
+    return n;
+}
+
+int pt_brdf_upload(pt_scene* s, int id, const double* table, size_t n) {
+    if (!s || !table) return fail(PT_ERR_INVALID, "pt_brdf_upload: null argument");
+    if (id < 0 || id >= PT_MAX_BRDF) return fail(PT_ERR_INVALID, "pt_brdf_upload: id out of range");
+    if (n != (size_t)PT_BRDF_TABLE_DOUBLES) return fail(PT_ERR_INVALID, "pt_brdf_upload: table must hold 3*90*90*180 doubles");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = s->d_brdf[id].ensure(n * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(s->d_brdf[id].p, table, n * sizeof(double), hipMemcpyHostToDevice));
+    s->ds.brdf[id] = (const double*)s->d_brdf[id].p;
+    return PT_OK;
+}
+
+int pt_brdf_load_file(pt_scene* s, int id, const char* path) {
+    if (!s || !path) return fail(PT_ERR_INVALID, "pt_brdf_load_file: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(PT_ERR_IO, std::string("cannot open ") + path);
+    int32_t dims[3];
+    if (fread(dims, sizeof(int32_t), 3, f) != 3) {
+        fclose(f);
+        return fail(PT_ERR_IO, "short read of BRDF header");
+    }
+    long long n = (long long)dims[0] * dims[1] * dims[2];
+    if (n != 90 * 90 * 180) {  // MatusikBRDF.h:92-100
+        fclose(f);
+        return fail(PT_ERR_IO, "Dimensions don't match");
+    }
+    std::vector<double> t((size_t)PT_BRDF_TABLE_DOUBLES);
+    size_t got = fread(t.data(), sizeof(double), t.size(), f);
+    fclose(f);
+    if (got != t.size()) return fail(PT_ERR_IO, "short read of BRDF table");
+    return pt_brdf_upload(s, id, t.data(), t.size());
+}
+
+int pt_set_partition(pt_scene* s, int rank, int world, int tile_w, int tile_h) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    return setup_partition(s, rank, world, tile_w, tile_h);
+}
+
+int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double* accum_dev, void* stream_) {
+    if (!s || !accum_dev) return fail(PT_ERR_INVALID, "pt_render_device: null argument");
+    if (n_iterations < 0 || first_iteration < 0) return fail(PT_ERR_INVALID, "pt_render_device: negative iteration range");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = check_measured_tables(s);
+    if (rc) return rc;
+    if ((rc = ensure_render_buffers(s))) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    const Partition P = s->part;
+    s->ev_used = 0;
+    s->last_paths = 0;
+    if (P.owned_tiles == 0 || n_iterations == 0) return PT_OK;
+    const int W = s->width, H = s->height;
+    const size_t J = (size_t)P.owned_tiles * kBlock;
+    double* xs = (double*)s->d_xs.p;
+    double* ys = (double*)s->d_ys.p;
+    int32_t* rs = (int32_t*)s->d_rowstart.p;
+    int32_t* npix = (int32_t*)s->d_npix.p;
+    double* samples = (double*)s->d_samples.p;
+    int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
+    for (int done = 0; done < n_iterations; done += s->batch) {
+        int B = std::min(s->batch, n_iterations - done);
+        int it0 = first_iteration + done;
+        hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, st, s->seed, W, H, it0, s->xstep, s->ystep, xs,
+                           ys, rs, npix);
+        if (s->ev.size() < s->ev_used + 2) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            s->ev.push_back(a);
+            s->ev.push_back(b);
+        }
+        HIP_TRY(hipEventRecord(s->ev[s->ev_used], st));
+        dim3 grid(P.owned_tiles, B);
+        if (s->estimator == PT_EST_NEE && s->has_measured)
+            hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, samples, J);
+        else if (s->estimator == PT_EST_NEE)
+            hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, samples, J);
+        else
+            hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, samples, J);
+        HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], st));
+        s->ev_used += 2;
+        hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, st, P, W, H, B, npix, samples, J, accum_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    s->last_paths = (double)n_iterations * (double)J;  // upper bound: includes out-of-image lanes of edge tiles
+    return PT_OK;
+}
+
+int pt_render(pt_scene* s, int first_iteration, int n_iterations, double* accum_host) {
+    if (!s || !accum_host) return fail(PT_ERR_INVALID, "pt_render: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t bytes = (size_t)s->width * s->height * 3 * sizeof(double);
+    int rc = s->d_accum.ensure(bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(s->d_accum.p, accum_host, bytes, hipMemcpyHostToDevice));
+    rc = pt_render_device(s, first_iteration, n_iterations, (double*)s->d_accum.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum_host, s->d_accum.p, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_get_stats(const pt_scene* s, pt_stats* out) {
+    if (!s || !out) return fail(PT_ERR_INVALID, "pt_get_stats: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    double ms = 0;
+    for (size_t i = 0; i + 1 < s->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(s->ev[i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1]));
+        ms += t;
+    }
+    out->paths = s->last_paths;
+    out->kernel_ms = ms;
+    out->launches = (double)(s->ev_used / 2);
+    return PT_OK;
+}
+
+int pt_intersect_batch(pt_scene* s, const double* rays6, int n, int skip, int32_t* idx, double* t) {
+    if (!s || !rays6 || !idx || !t || n < 0) return fail(PT_ERR_INVALID, "pt_intersect_batch: bad argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    double *d_r = nullptr, *d_t = nullptr;
+    int32_t* d_i = nullptr;
+    HIP_TRY(hipMalloc(&d_r, sizeof(double) * 6 * n));
+    HIP_TRY(hipMalloc(&d_t, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&d_i, sizeof(int32_t) * n));
+    HIP_TRY(hipMemcpy(d_r, rays6, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_intersect_batch, dim3((n + 255) / 256), dim3(256), 0, 0, s->ds, d_r, n, skip, d_i, d_t);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(idx, d_i, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t, d_t, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_r);
+    (void)hipFree(d_t);
+    (void)hipFree(d_i);
+    return PT_OK;
+}
+
+int pt_intersect_all(pt_scene* s, const double* rays6, int n, double* t_all) {
+    if (!s || !rays6 || !t_all || n < 0) return fail(PT_ERR_INVALID, "pt_intersect_all: bad argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nb = s->bodies.size();
+    double *d_r = nullptr, *d_t = nullptr;
+    HIP_TRY(hipMalloc(&d_r, sizeof(double) * 6 * n));
+    HIP_TRY(hipMalloc(&d_t, sizeof(double) * n * nb));
+    HIP_TRY(hipMemcpy(d_r, rays6, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_intersect_all, dim3((n + 255) / 256), dim3(256), 0, 0, s->ds, d_r, n, d_t);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(t_all, d_t, sizeof(double) * n * nb, hipMemcpyDeviceToHost));
+    (void)hipFree(d_r);
+    (void)hipFree(d_t);
+    return PT_OK;
+}
+
+int pt_trace_paths(pt_scene* s, const int32_t* it_idx2, const double* xy, int n, double* rgb, int32_t* nrec,
+                   int32_t* bodies, double* points, int32_t* visible, int32_t* used) {
+    if (!s || !it_idx2 || !xy || n < 0) return fail(PT_ERR_INVALID, "pt_trace_paths: bad argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = check_measured_tables(s);
+    if (rc) return rc;
+    int32_t *d_ii = nullptr, *d_nrec = nullptr, *d_bod = nullptr, *d_vis = nullptr, *d_used = nullptr;
+    double *d_xy = nullptr, *d_rgb = nullptr, *d_pts = nullptr;
+    HIP_TRY(hipMalloc(&d_ii, sizeof(int32_t) * 2 * n));
+    HIP_TRY(hipMalloc(&d_xy, sizeof(double) * 2 * n));
+    HIP_TRY(hipMalloc(&d_rgb, sizeof(double) * 3 * n));
+    HIP_TRY(hipMalloc(&d_nrec, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&d_bod, sizeof(int32_t) * 5 * n));
+    HIP_TRY(hipMalloc(&d_pts, sizeof(double) * 15 * n));
+    HIP_TRY(hipMalloc(&d_vis, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&d_used, sizeof(int32_t) * n));
+    HIP_TRY(hipMemcpy(d_ii, it_idx2, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_xy, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    dim3 grid((n + kBlock - 1) / kBlock);
+    if (s->estimator == PT_EST_NEE && s->has_measured)
+        hipLaunchKernelGGL((k_trace_paths<kEstNEE, true>), grid, dim3(kBlock), 0, 0, s->ds, d_ii, d_xy, n, d_rgb, d_nrec,
+                           d_bod, d_pts, d_vis, d_used);
+    else if (s->estimator == PT_EST_NEE)
+        hipLaunchKernelGGL((k_trace_paths<kEstNEE, false>), grid, dim3(kBlock), 0, 0, s->ds, d_ii, d_xy, n, d_rgb, d_nrec,
+                           d_bod, d_pts, d_vis, d_used);
+    else
+        hipLaunchKernelGGL((k_trace_paths<kEstPT, false>), grid, dim3(kBlock), 0, 0, s->ds, d_ii, d_xy, n, d_rgb, d_nrec,
+                           d_bod, d_pts, d_vis, d_used);
+    HIP_TRY(hipGetLastError());
+    if (rgb) HIP_TRY(hipMemcpy(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    if (nrec) HIP_TRY(hipMemcpy(nrec, d_nrec, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (bodies) HIP_TRY(hipMemcpy(bodies, d_bod, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost));
+    if (points) HIP_TRY(hipMemcpy(points, d_pts, sizeof(double) * 15 * n, hipMemcpyDeviceToHost));
+    if (visible) HIP_TRY(hipMemcpy(visible, d_vis, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (used) HIP_TRY(hipMemcpy(used, d_used, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ii);
+    (void)hipFree(d_xy);
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_nrec);
+    (void)hipFree(d_bod);
+    (void)hipFree(d_pts);
+    (void)hipFree(d_vis);
+    (void)hipFree(d_used);
+    return PT_OK;
+}
+
+int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t* row_len, int32_t* nrows) {
+    if (!s || !ys || !xs || !row_len || !nrows) return fail(PT_ERR_INVALID, "pt_frame_layout: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_render_buffers(s);
+    if (rc) return rc;
+    const int W = s->width, H = s->height;
+    int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
+    HIP_TRY(hipMemset(s->d_xs.p, 0xFF, sizeof(double) * (size_t)W * H));
+    HIP_TRY(hipMemset(s->d_ys.p, 0xFF, sizeof(double) * (size_t)H));
+    hipLaunchKernelGGL(k_frame_layout, dim3(1), dim3(layout_threads), 0, 0, s->seed, W, H, iteration, s->xstep, s->ystep,
+                       (double*)s->d_xs.p, (double*)s->d_ys.p, (int32_t*)s->d_rowstart.p, (int32_t*)s->d_npix.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> rs(H + 1);
+    HIP_TRY(hipMemcpy(xs, s->d_xs.p, sizeof(double) * (size_t)W * H, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ys, s->d_ys.p, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rs.data(), s->d_rowstart.p, sizeof(int32_t) * (H + 1), hipMemcpyDeviceToHost));
+    int nr = 0;
+    for (int r = 0; r < H; ++r) {
+        row_len[r] = rs[r + 1] - rs[r];
+        if (row_len[r] > 0) nr = r + 1;
+    }
+    *nrows = nr;
+    return PT_OK;
+}
+
+int pt_rng_fill(uint64_t seed, uint32_t iteration, uint32_t domain, uint32_t index, int n, int32_t* k, double* u) {
+    if (n < 0 || !k || !u) return fail(PT_ERR_INVALID, "pt_rng_fill: bad argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(g_device));
+    int32_t* d_k = nullptr;
+    double* d_u = nullptr;
+    HIP_TRY(hipMalloc(&d_k, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&d_u, sizeof(double) * n));
+    hipLaunchKernelGGL(k_rng_fill, dim3(1), dim3(64), 0, 0, seed, iteration, domain, index, n, d_k, d_u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(k, d_k, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(u, d_u, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_k);
+    (void)hipFree(d_u);
+    return PT_OK;
+}
+
+int pt_brdf_lookup(pt_scene* s, int id, const double* angles4, int n, double* rgb, int32_t* ind) {
+    if (!s || !angles4 || !rgb || !ind || n < 0) return fail(PT_ERR_INVALID, "pt_brdf_lookup: bad argument");
+    if (id < 0 || id >= PT_MAX_BRDF || !s->d_brdf[id].p) return fail(PT_ERR_INVALID, "pt_brdf_lookup: table not uploaded");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    double *d_a = nullptr, *d_rgb = nullptr;
+    int32_t* d_ind = nullptr;
+    HIP_TRY(hipMalloc(&d_a, sizeof(double) * 4 * n));
+    HIP_TRY(hipMalloc(&d_rgb, sizeof(double) * 3 * n));
+    HIP_TRY(hipMalloc(&d_ind, sizeof(int32_t) * n));
+    HIP_TRY(hipMemcpy(d_a, angles4, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_brdf_lookup, dim3((n + 255) / 256), dim3(256), 0, 0, (const double*)s->d_brdf[id].p, d_a, n, d_rgb,
+                       d_ind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ind, d_ind, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_a);
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_ind);
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle (oracle/cpu_ref.c)
+and the committed golden vectors.  Integer/index results and FP64 radiance are compared bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import path_tracer_amd as pt
+from _oracle import EST_NEE, EST_PT, MODE_PIXEL
+from conftest import GOLDEN, same_bits
+
+pytestmark = pytest.mark.gpu
+EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT}
+
+
+def oracle_scene(port, renderer, W, H, seed, flags=0, tables=None):
+    bodies, n = renderer.bodies()  # as stored by the product (normals normalised)
+    import _oracle
+
+    ob = (_oracle.Body * n)()
+    for i in range(n):
+        for f, _ in _oracle.Body._fields_:
+            src = getattr(bodies[i], "reserved" if f == "pad" else f)
+            setattr(ob[i], f, src)
+    cam = _oracle.Camera()
+    for f in ("origin", "topleft", "topright", "bottomleft"):
+        for k in range(3):
+            getattr(cam, f)[k] = getattr(renderer.desc.camera, f)[k]
+    return port.scene(ob, n, cam, W, H, renderer.desc.estimator, seed=seed, flags=flags, tables=tables)
+
+
+def test_rng_contract(port):
+    for (seed, it, dom, idx) in ((1, 0, 0, 0), (7, 3, 0, 123456), (2**63 + 5, 7199, 1, 767), (0, 0, 2, 0), (9, 1, 3, 4)):
+        k, u = pt.rng_fill(seed, it, dom, idx, 257)
+        k0, u0 = port.rng_fill(seed, it, dom, idx, 257)
+        assert np.array_equal(k, k0)
+        assert same_bits(u, u0)
+
+
+def test_intersect_bit_exact_on_fixed_ray_batch(port):
+    z = np.load(os.path.join(GOLDEN, "intersect.npz"))
+    for name in ("main32", "nee15"):
+        r = pt.Renderer(pt.preset(name, 16, 16))
+        rays = z[f"{name}_rays"]
+        assert same_bits(r.intersect_all(rays), z[f"{name}_t_all"])  # vs the reference's Shape::intersect
+        idx, t = r.intersect_batch(rays)
+        s = oracle_scene(port, r, 16, 16, 1)
+        _, idx0, t0 = port.intersect(s, rays)
+        assert np.array_equal(idx, idx0) and same_bits(t, t0)
+        if name == "nee15":
+            assert np.array_equal(idx, z["nee15_nearest_idx"])  # the reference's own scan loop
+            idx2, t2 = r.intersect_batch(rays, skip=14)
+            _, idx3, t3 = port.intersect(s, rays, skip=14)
+            assert np.array_equal(idx2, idx3) and same_bits(t2, t3)
+        r.close()
+
+
+def test_intersect_large_random_batch(port):
+    rng = np.random.default_rng(5)
+    n = 200_000
+    o = np.stack([rng.uniform(-1.8, 1.8, n), rng.uniform(-2.4, 4.4, n), rng.uniform(-0.45, 2.4, n)], axis=1)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d *= rng.uniform(0.01, 1.0, size=(n, 1))
+    rays = np.concatenate([o, d], axis=1)
+    for name in ("main32", "nee15"):
+        r = pt.Renderer(pt.preset(name, 16, 16))
+        idx, t = r.intersect_batch(rays)
+        _, idx0, t0 = port.intersect(oracle_scene(port, r, 16, 16, 1), rays)
+        assert np.array_equal(idx, idx0) and same_bits(t, t0)
+        r.close()
+
+
+@pytest.mark.parametrize("W,H,seed", [(24, 16, 7), (1024, 5, 5), (3, 700, 11), (1, 1, 3)])
+def test_frame_layout(port, W, H, seed):
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=seed))
+    s = oracle_scene(port, r, W, H, seed)
+    for it in (0, 1, 17, 4099):
+        nrows, ys, xs, rl = r.frame_layout(it)
+        rows0, ys0, xs0, rl0 = port.frame_layout(s, it)
+        assert np.array_equal(rl, rl0)
+        assert same_bits(ys[:rows0], ys0[:rows0])
+        for row in range(rows0):
+            assert same_bits(xs[row, : rl0[row]], xs0[row, : rl0[row]])
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["nee15", "main32", "pt15"])
+def test_paths_match_oracle(port, name):
+    rng = np.random.default_rng(11)
+    n = 20000
+    r = pt.Renderer(pt.preset(name, 64, 64, seed=99))
+    s = oracle_scene(port, r, 64, 64, 99)
+    it_idx = np.stack([rng.integers(0, 7200, n), rng.integers(0, 1 << 20, n)], axis=1).astype(np.int32)
+    xy = rng.uniform(0, 1, size=(n, 2))
+    g = r.trace_paths(it_idx, xy)
+    o = port.trace_paths(s, it_idx, xy)
+    assert np.array_equal(g["nrec"], o["nrec"])
+    assert np.array_equal(g["bodies"], o["bodies"])
+    assert np.array_equal(g["draws"], o["draws"])
+    if name == "nee15":
+        assert np.array_equal(g["visible"], o["visible"])
+    # offset points: the oracle mirrors the reference's x87 islands, the GPU is plain FP64
+    np.testing.assert_allclose(g["points"], o["points"], rtol=1e-12, atol=1e-13)
+    assert same_bits(g["rgb"], o["rgb"])  # radiance is a function of the discrete path only here
+    r.close()
+
+
+def test_golden_frames(port):
+    z = np.load(os.path.join(GOLDEN, "frames.npz"))
+    with open(os.path.join(GOLDEN, "frames.json")) as f:
+        meta = [m for m in json.load(f) if m["mode"] == MODE_PIXEL]
+    assert len(meta) == 8
+    for m in meta:
+        r = pt.Renderer(pt.preset(m["scene"], m["W"], m["H"], seed=m["seed"]))
+        buf = r.render(m["first"], m["n_it"])
+        assert same_bits(buf, z[m["key"]]), m["key"]  # vs the reference's own Renderer::iterate
+        r.close()
+
+
+@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40)])
+def test_frames_match_oracle(port, name, W, H, n_it):
+    r = pt.Renderer(pt.preset(name, W, H, seed=2025))
+    s = oracle_scene(port, r, W, H, 2025)
+    want, _ = port.render(s, MODE_PIXEL, 3, n_it)
+    got = r.render(3, n_it)
+    assert same_bits(got, want)
+    # the result does not depend on how the iterations are split into calls
+    a = r.render(3, 2)
+    r.render(5, n_it - 2, a)
+    assert same_bits(a, want)
+    r.close()
+
+
+def test_short_row_shift_at_full_width(port):
+    # W = 1024: about 1 % of rows are one pixel short and shift every later pixel (main.cpp:350,362)
+    W, H = 1024, 6
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=5))
+    s = oracle_scene(port, r, W, H, 5)
+    short_its = [it for it in range(64) if (port.frame_layout(s, it)[3][: port.frame_layout(s, it)[0]] == W - 1).any()]
+    assert short_its
+    it = short_its[0]
+    want, _ = port.render(s, MODE_PIXEL, it, 1)
+    assert same_bits(r.render(it, 1), want)
+    r.close()
+
+
+def test_partition_tiles_sum_to_whole():
+    W, H = 100, 37
+    whole = pt.Renderer(pt.preset("nee15", W, H, seed=4)).render(0, 3)
+    acc = np.zeros_like(whole)
+    for world in (2, 3):
+        acc[:] = 0
+        owned = np.zeros((H, W), dtype=np.int32)
+        for rank in range(world):
+            r = pt.Renderer(pt.preset("nee15", W, H, seed=4))
+            r.set_partition(rank, world, 32, 8)
+            part = r.render(0, 3)
+            owned += (part != 0).any(axis=2)
+            acc += part
+            r.close()
+        assert same_bits(acc, whole)
+        assert owned.max() == 1
+
+
+def test_true_light_centre_flag(port):
+    d = pt.preset("nee15", 48, 32, seed=8)
+    d.flags = pt.F_LIGHT_TRUE_CENTER
+    r = pt.Renderer(d)
+    s = oracle_scene(port, r, 48, 32, 8, flags=1)
+    want, _ = port.render(s, MODE_PIXEL, 0, 4)
+    assert same_bits(r.render(0, 4), want)
+    r.close()
+
+
+def test_measured_brdf_lookup_and_render(port):
+    z = np.load(os.path.join(GOLDEN, "brdf.npz"))
+    d = pt.preset("nee15_measured", 40, 30, seed=6)
+    r = pt.Renderer(d)
+    index_table = np.concatenate([np.arange(pt.BRDF_TABLE_DOUBLES // 3, dtype=np.float64)] * 3)
+    r.brdf_upload(0, index_table)
+    rgb, ind = r.brdf_lookup(0, z["angles"])
+    want_ind = np.rint(z["rgb"][:, 0] * 1500.0).astype(np.int64)
+    # device libm and glibc round sin/cos/acos/atan2 differently in the last place: an angle on a
+    # bin edge may land in the neighbouring bin
+    bad = np.nonzero(ind != want_ind)[0]
+    assert len(bad) <= 2, bad
+    ok = ind == want_ind
+    assert same_bits(rgb[ok], z["rgb"][ok])
+    assert ind[:4].tolist() == [684585, 0, 1410930, 8010]
+    tables = [pt.synthetic_brdf_table(k) for k in range(4)]
+    for k, t in enumerate(tables):
+        r.brdf_upload(k, t)
+    s = oracle_scene(port, r, 40, 30, 6, tables=tables)
+    want, _ = port.render(s, MODE_PIXEL, 0, 4)
+    got = r.render(0, 4)
+    diff = np.abs(got - want) > 1e-9 * np.maximum(1.0, np.abs(want))
+    assert diff.mean() < 2e-3  # bin-edge lookups only
+    assert np.abs(got).sum() > 0 and (got != r.render(0, 0)).any()
+    r.close()
+
+
+def test_errors_are_reported_not_fatal():
+    d = pt.preset("nee15", 8, 8)
+    d.body_count = 0
+    with pytest.raises(pt.PtError):
+        pt.Renderer(d)
+    r = pt.Renderer(pt.preset("nee15_measured", 8, 8))
+    with pytest.raises(pt.PtError):  # tables not uploaded
+        r.render(0, 1)
+    with pytest.raises(pt.PtError):
+        r.set_partition(0, 1, 10, 10)  # tile must hold 256 pixels
+    r.close()
