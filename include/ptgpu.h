@@ -141,6 +141,13 @@ int pt_frame_layout(pt_scene* scene, int iteration, double* ys, double* xs, int3
  * main.cpp:19-22) of stream (seed, iteration, domain, index). */
 int pt_rng_fill(uint64_t seed, uint32_t iteration, uint32_t domain, uint32_t index, int n, int32_t* k, double* u);
 
+/* The double-arithmetic emulation of the reference's x87 extended-precision expressions, evaluated
+ * on the host (on_device = 0) or on the GPU.  kind 0: (double)(1.0L / a)  main.cpp:93;
+ * 1: (double)(u*2.0L - 1.0L) with u = k/2147483647.0, k = (int)a  main.cpp:108;
+ * 2: (double)(a*1.0000001L), 3: (double)(a*0.9999999L)  main.cpp:396,400;
+ * 4: Glass theta2 with eta = a, theta1 = b  main.cpp:292. */
+int pt_x87_eval(int kind, int on_device, const double* a, const double* b, int n, double* out);
+
 /* MatusikBRDF::lookup_brdf_val (MatusikBRDF.h:50-80) on an uploaded table: angles4[n][4] =
  * theta_in, phi_in, theta_out, phi_out -> rgb[n][3], ind[n] (table index). */
 int pt_brdf_lookup(pt_scene* scene, int brdf_id, const double* angles4, int n, double* rgb, int32_t* ind);

@@ -622,6 +622,22 @@ void por_trace_paths(const por_scene* s, const int* it_idx2, const double* xy, i
     }
 }
 
+/* The reference's extended-precision expressions, evaluated with real x87 long double. */
+void por_x87(int kind, const double* a, const double* b, int n, double* out) {
+    for (int i = 0; i < n; i++) {
+        switch (kind) {
+            case 0: out[i] = (double)(1.0L / a[i]); break;                                        /* main.cpp:93 */
+            case 1: out[i] = (double)(((int)a[i] / (double)2147483647) * 2.0L - 1.0L); break;      /* main.cpp:108 */
+            case 2: out[i] = (double)(a[i] * 1.0000001L); break;                                  /* main.cpp:396 */
+            case 3: out[i] = (double)(a[i] * 0.9999999L); break;                                  /* main.cpp:400 */
+            default: {                                                                             /* main.cpp:292 */
+                double eta = a[i], theta1 = b[i];
+                out[i] = (double)sqrtl(1.0L - (eta * eta) * (1.0L - (theta1 * theta1)));
+            }
+        }
+    }
+}
+
 /* k values of a stream (contract check against the product's generator). */
 void por_rng_fill(uint64_t seed, uint32_t it, uint32_t dom, uint32_t idx, int n, int32_t* k_out, double* u_out) {
     ptor_rng r;

@@ -120,7 +120,9 @@ def synthetic_brdf_table(table_id, negative_fraction=0.03):
     of entries is negative to exercise the below-horizon rule (MatusikBRDF.h:73-79)."""
     n = BRDF_TABLE_DOUBLES
     idx = np.arange(n, dtype=np.uint64)
-    x = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(table_id + 1) * np.uint64(0xD1B54A32D192ED03)
+    with np.errstate(over="ignore"):
+        salt = np.array([table_id + 1], dtype=np.uint64) * np.uint64(0xD1B54A32D192ED03)
+        x = idx * np.uint64(0x9E3779B97F4A7C15) + salt
     x ^= x >> np.uint64(30)
     x *= np.uint64(0xBF58476D1CE4E5B9)
     x ^= x >> np.uint64(27)

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pt_x87.hpp"
+
 namespace ptd {
 
 #define PTD_INLINE __device__ __forceinline__
@@ -37,11 +39,9 @@ PTD_INLINE V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 PTD_INLINE V3 muls(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
 // dot: x*v.x + y*v.y + z*v.z, left to right (main.cpp:96-98)
 PTD_INLINE double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-// normalize = divs(sqrt(dot)) = muls(1.0L / s) (main.cpp:92-102).  The reference forms the
-// reciprocal in x87 extended precision and then narrows it; a correctly rounded double
-// division gives the same double except when the 64-bit-mantissa quotient falls exactly on a
-// double midpoint (about 1 in 4096 reciprocals differs by one ulp).
-PTD_INLINE V3 normalize(V3 a) { return muls(a, 1.0 / sqrt(dot(a, a))); }
+// normalize = divs(sqrt(dot)) = muls(1.0L / s) (main.cpp:92-102): the reciprocal is formed in
+// x87 extended precision and narrowed to the double parameter of muls.
+PTD_INLINE V3 normalize(V3 a) { return muls(a, ptx::x87_recip(sqrt(dot(a, a)))); }
 
 // ---- random numbers --------------------------------------------------------------------
 // Stream contract: xoshiro128+ state seeded from (seed, iteration, domain, index) by three
@@ -93,6 +93,10 @@ PTD_INLINE double unif(Draws& d) {
     d.count++;
     return k_to_unit(rng_next(d.rng));
 }
+// unifRand()*2.0L-1.0L narrowed to double (main.cpp:108).  For u >= 2^-13 the extended-precision
+// difference is exact, and for the 2^18 smaller draws an exhaustive check shows that the plain
+// double expression rounds to the same value, so no emulation is needed here.
+PTD_INLINE double unif_pm1(Draws& d) { return unif(d) * 2.0 - 1.0; }
 
 // ---- scene records ---------------------------------------------------------------------
 struct DGeom {  // 64 bytes, what the nearest-hit scan reads
@@ -181,9 +185,9 @@ PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, in
 PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
     V3 v;
     do {
-        v.z = unif(dr) * 2.0 - 1.0;
-        v.y = unif(dr) * 2.0 - 1.0;
-        v.x = unif(dr) * 2.0 - 1.0;
+        v.z = unif_pm1(dr);
+        v.y = unif_pm1(dr);
+        v.x = unif_pm1(dr);
     } while (dot(v, v) > 1.0);
     if (dot(v, n) < 0.0) v = muls(v, -1.0);
     return v;
@@ -196,7 +200,7 @@ PTD_INLINE V3 bounce_chrome(V3 d, V3 n) {
 }
 
 // Glass::bounce main.cpp:279-305.  theta1 = fabs(..) >= 0 always, so internal = ior,
-// external = 1.  (The reference evaluates theta2 in x87 extended precision; here it is double.)
+// external = 1.  theta2 is an x87 extended-precision expression (ptx::x87_glass_theta2).
 PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double refl) {
     double theta1 = fabs(dot(d, n));
     double internalIndex = ior, externalIndex = 1.0;
@@ -205,7 +209,7 @@ PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double refl) {
         externalIndex = ior;
     }
     double eta = externalIndex / internalIndex;
-    double theta2 = sqrt(1.0 - (eta * eta) * (1.0 - (theta1 * theta1)));
+    double theta2 = ptx::x87_glass_theta2(eta, theta1);
     double rs = (externalIndex * theta1 - internalIndex * theta2) / (externalIndex * theta1 + internalIndex * theta2);
     double rp = (internalIndex * theta1 - externalIndex * theta2) / (internalIndex * theta1 + externalIndex * theta2);
     double reflectance = (rs * rs + rp * rp);
@@ -224,18 +228,6 @@ PTD_INLINE V3 shape_normal(const DGeom& g, V3 point) {
     if (g.shape == kPlane) return mk(g.nx, g.ny, g.nz);
     return normalize(sub(point, mk(g.cx, g.cy, g.cz)));
 }
-
-// mint*1.0000001L and mint*0.9999999L (main.cpp:396,400): the literals have 64-bit
-// significands; each is split into two doubles (hi + lo exactly) and the product is rounded
-// once, which reproduces the narrowed x87 product up to double-rounding ties.
-PTD_INLINE double mul_ext(double t, double chi, double clo) {
-    double p = t * chi;
-    double e1 = __builtin_fma(t, chi, -p);  // exact error of the product
-    double e2 = t * clo;
-    return p + (e1 + e2);
-}
-PTD_INLINE double mul_1p0000001(double t) { return mul_ext(t, 0x1.000001ad7f29bp+0, -0x1.0d8p-54); }
-PTD_INLINE double mul_0p9999999(double t) { return mul_ext(t, 0x1.fffffca501acbp-1, -0x1.e58p-55); }
 
 // ---- measured BRDF: MatusikBRDF.h ------------------------------------------------------
 PTD_INLINE void brdf_normalize(double* v) {  // :124-130
@@ -391,7 +383,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         V3 normal = shape_normal(g, point);
         V3 dir = bounce(m, dr, d, normal);
         // main.cpp:394-401 (the comparison is against the float 0.0f)
-        double tt = (dot(dir, d) > 0.0) ? mul_1p0000001(mint) : mul_0p9999999(mint);
+        double tt = (dot(dir, d) > 0.0) ? ptx::x87_mul_1p0000001(mint) : ptx::x87_mul_0p9999999(mint);
         point = add(o, muls(d, tt));
         rec.put(n, point, hit);
         o = point;

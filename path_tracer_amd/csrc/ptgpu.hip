@@ -260,6 +260,23 @@ __global__ void k_rng_fill(uint64_t seed, uint32_t it, uint32_t dom, uint32_t id
     }
 }
 
+// kind: 0 recip, 1 2u-1 (a = k), 2 *1.0000001L, 3 *0.9999999L, 4 glass theta2(eta = a, theta1 = b)
+PTX_INLINE double x87_eval(int kind, double a, double b) {
+    switch (kind) {
+        case 0: return ptx::x87_recip(a);
+        case 1: return ptx::x87_2u_minus_1((double)(int32_t)a / 2147483647.0, (int32_t)a);
+        case 2: return ptx::x87_mul_1p0000001(a);
+        case 3: return ptx::x87_mul_0p9999999(a);
+        default: return ptx::x87_glass_theta2(a, b);
+    }
+}
+
+__global__ void k_x87_eval(int kind, const double* __restrict__ a, const double* __restrict__ b, int n,
+                           double* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x87_eval(kind, a[i], b[i]);
+}
+
 __global__ void k_brdf_lookup(const double* __restrict__ table, const double* __restrict__ angles4, int n,
                               double* __restrict__ rgb, int32_t* __restrict__ ind) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -751,6 +768,29 @@ int pt_rng_fill(uint64_t seed, uint32_t iteration, uint32_t domain, uint32_t ind
     HIP_TRY(hipMemcpy(u, d_u, sizeof(double) * n, hipMemcpyDeviceToHost));
     (void)hipFree(d_k);
     (void)hipFree(d_u);
+    return PT_OK;
+}
+
+int pt_x87_eval(int kind, int on_device, const double* a, const double* b, int n, double* out) {
+    if (!a || !b || !out || n < 0 || kind < 0 || kind > 4) return fail(PT_ERR_INVALID, "pt_x87_eval: bad argument");
+    if (!on_device) {
+        for (int i = 0; i < n; ++i) out[i] = x87_eval(kind, a[i], b[i]);
+        return PT_OK;
+    }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(g_device));
+    double *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc(&d_a, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&d_b, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&d_o, sizeof(double) * n));
+    HIP_TRY(hipMemcpy(d_a, a, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, b, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_x87_eval, dim3((n + 255) / 256), dim3(256), 0, 0, kind, d_a, d_b, n, d_o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_a);
+    (void)hipFree(d_b);
+    (void)hipFree(d_o);
     return PT_OK;
 }
 

@@ -189,15 +189,34 @@ def test_measured_brdf_lookup_and_render(port):
     ok = ind == want_ind
     assert same_bits(rgb[ok], z["rgb"][ok])
     assert ind[:4].tolist() == [684585, 0, 1410930, 8010]
+    # Rendering.  When a path re-hits the floor at t ~ 1e-14 the outgoing direction sits exactly on
+    # the pole of the half/difference parametrisation; phi_diff is then rounding noise of libm's
+    # sin/cos/atan2, and glibc and the device library fall on opposite sides of the 0/pi cut (cyclic
+    # neighbour bins 0 and 179).  With hash-noise tables such a lookup changes the sample, so a
+    # small fraction of pixels may differ; everything else is bit-exact.
     tables = [pt.synthetic_brdf_table(k) for k in range(4)]
     for k, t in enumerate(tables):
         r.brdf_upload(k, t)
     s = oracle_scene(port, r, 40, 30, 6, tables=tables)
     want, _ = port.render(s, MODE_PIXEL, 0, 4)
     got = r.render(0, 4)
-    diff = np.abs(got - want) > 1e-9 * np.maximum(1.0, np.abs(want))
-    assert diff.mean() < 2e-3  # bin-edge lookups only
-    assert np.abs(got).sum() > 0 and (got != r.render(0, 0)).any()
+    differs = (got.view(np.uint64) != want.view(np.uint64)).any(axis=2)
+    assert differs.mean() < 0.01
+    assert np.abs(got).sum() > 0
+    # per path: same bodies, same visibility, same draw count everywhere; radiance equal except on
+    # paths with such a degenerate re-hit
+    rng = np.random.default_rng(12)
+    n = 20000
+    it_idx = np.stack([rng.integers(0, 7200, n), rng.integers(0, 1 << 20, n)], axis=1).astype(np.int32)
+    xy = rng.uniform(0, 1, size=(n, 2))
+    g = r.trace_paths(it_idx, xy)
+    o = port.trace_paths(s, it_idx, xy)
+    assert np.array_equal(g["bodies"], o["bodies"]) and np.array_equal(g["visible"], o["visible"])
+    assert np.array_equal(g["draws"], o["draws"])
+    bad = (g["rgb"].view(np.uint64) != o["rgb"].view(np.uint64)).any(axis=1)
+    assert bad.mean() < 2e-3
+    rehit = (g["bodies"][:, 1:] == g["bodies"][:, :-1]).any(axis=1)
+    assert rehit[bad].all()
     r.close()
 
 
