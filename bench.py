@@ -1,0 +1,190 @@
+"""Headline benchmark: paths/s of the NEE estimator, 1024x768 at 7200 iterations (the reference's
+path_tracing_1024x768x7200i workload), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one complete render of the workload into a zeroed FP64 accumulator resident in HBM:
+every rank renders its interleaved 32x8 destination tiles, then one RCCL all-reduce (sum) of the
+W*H*3 FP64 accumulators makes the whole frame available on every rank.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# Algorithmic work per path of the 15-body NEE scene: 5 gather scans of 15 bodies + 5 shadow scans of
+# 14 bodies at 14 flop per plane test and 19 per sphere test = 5*245 + 5*226.
+FLOP_PER_PATH_NEE15 = 2355.0
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flop
+
+
+def cpu_baseline(width, height, seconds_target):
+    """The CPU partner timed on this host's cores: the reference's own Renderer::iterate()
+    (oracle/_ref) when that build is present, else the C restatement.  Bounded sample."""
+    import _oracle
+
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
+    paths_per_it = width * height
+    est_rate = 0.3e6 * cores  # paths/s, to size the sample
+    iters = max(1, int(seconds_target * est_rate / (paths_per_it * cores)))
+    if _oracle.Ref.available():
+        ref = _oracle.Ref()
+        secs, _ = ref.time_iterate(1, width, height, iters, cores, seed=1)
+        kind = "reference"
+    else:
+        import path_tracer_amd as pt
+
+        port = _oracle.Port()
+        d = pt.preset("nee15", width, height)
+        stored = (_oracle.Body * d.body_count)()
+        for i in range(d.body_count):
+            b = pt.Body()
+            b.__dict__.update()
+            tmp = d.bodies[i]
+            pt.lib().pt_body_construct(tmp)
+            for f, _ in _oracle.Body._fields_:
+                setattr(stored[i], f, getattr(tmp, "reserved" if f == "pad" else f))
+        cam = _oracle.Camera()
+        for f in ("origin", "topleft", "topright", "bottomleft"):
+            for k in range(3):
+                getattr(cam, f)[k] = getattr(d.camera, f)[k]
+        s = port.scene(stored, d.body_count, cam, width, height, _oracle.EST_NEE, seed=1)
+        secs, _ = port.time_render(s, iters, cores)
+        kind = "port"
+    paths = float(paths_per_it) * iters * cores
+    return {
+        "value": paths / secs,
+        "unit": "paths/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"next_event 15-body scene {width}x{height}, {iters} iteration(s) on each of {cores} "
+                  f"independent single-thread workers ({paths:.3g} paths, {secs:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--iterations", type=int, default=7200)
+    ap.add_argument("--scene", default="nee15")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import path_tracer_amd as pt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    pt.set_device(local_rank)
+
+    W, H, IT = args.width, args.height, args.iterations
+    r = pt.Renderer(pt.preset(args.scene, W, H, seed=1))
+    r.set_partition(rank, world, 32, 8)
+    accum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        accum.zero_()
+        r.render_device(0, IT, accum.data_ptr(), stream)
+        if world > 1:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, launches = 0.0, 0.0
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            torch.cuda.synchronize()
+            st = r.stats()  # HIP events recorded on the render stream around every estimator launch
+            kernel_ms += st["kernel_ms"]
+            launches += st["launches"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    paths = float(W) * H * IT * args.steps
+    checksum = float(accum.sum().item()) / (W * H * 3 * IT)
+    if rank == 0:
+        out = {
+            "metric": "paths/sec (whole node), 1024x768 NEE",
+            "value": paths / elapsed,
+            "unit": "paths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"next_event.cpp 15-body scene, {W}x{H}, {IT} iterations (spp), seed 1",
+                "rays_per_path": 10,
+                "rays_per_s": 10 * paths / elapsed,
+                "partition": f"interleaved 32x8 tiles over {world} GPU(s) + RCCL all-reduce of FP64 accumulators",
+                "mean_radiance": checksum,
+            },
+        }
+        if world == 1 and launches > 0:
+            paths_per_launch = float(W) * H * IT * args.steps / launches
+            avg_ms = kernel_ms / launches
+            achieved = paths_per_launch * FLOP_PER_PATH_NEE15 / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "valu_fp64",
+                "achieved": achieved,
+                "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_VALU_PEAK_TFLOPS,
+                "frac_of_no_fma_ceiling": achieved / (FP64_VALU_PEAK_TFLOPS / 2),
+                "traffic": None,
+                "kernel": "k_trace<NEE>",
+                "avg_launch_ms": avg_ms,
+                "launches": launches,
+                "flop_per_path": FLOP_PER_PATH_NEE15,
+            }
+            if not args.no_cpu:
+                cb = cpu_baseline(W, H, args.cpu_seconds)
+                out["cpu_baseline"] = cb
+                out["config"]["gpu_over_cpu"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()
