@@ -17,7 +17,7 @@ namespace ptd {
 constexpr int kMaxDepth = 5;  // trace() returns at n > 4: main.cpp:368
 constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
-enum { kSphere = 0, kPlane = 1 };
+enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4 };  // 2..4: device-only, normal = +-e_k
 enum { kDiffuse = 0, kChrome = 1, kGlass = 2, kMeasured = 3 };
 enum { kEstPT = 0, kEstNEE = 1 };
 enum { kDomPixel = 0, kDomRow = 1, kDomFrame = 2, kDomSeq = 3 };
@@ -82,8 +82,18 @@ PTD_INLINE int32_t rng_next(Rng& r) {
     return (int32_t)(result >> 1);
 }
 
-// rand() / double(RAND_MAX) with RAND_MAX = 2147483647: a correctly rounded division.
-PTD_INLINE double k_to_unit(int32_t k) { return (double)k / 2147483647.0; }
+// rand() / double(RAND_MAX) with RAND_MAX = 2147483647, i.e. the correctly rounded quotient
+// k / 2147483647.0.  One multiplication by the rounded reciprocal plus one exact-residual
+// correction yields that quotient for every k in [0, 2^31-1] (checked exhaustively over all 2^31
+// draws, tests/test_rng_exhaustive.py), at 3 VALU operations instead of a ~15-instruction division.
+PTD_INLINE double k_to_unit(int32_t k) {
+    const double D = 2147483647.0;
+    const double c = 0x1.00000002p-31;  // RN(1 / D)
+    double kd = (double)k;
+    double q0 = kd * c;
+    double r = __builtin_fma(-q0, D, kd);  // exact residual
+    return __builtin_fma(r, c, q0);
+}
 
 struct Draws {
     Rng rng;
@@ -154,12 +164,37 @@ PTD_INLINE double intersect_sphere(const DGeom& g, V3 o, V3 d) {
     double c = (dx * dx + dy * dy + dz * dz) - g.nx;
     double disc = (b * b) - c;
     double t = -1.0;
-    if (disc > 0.0) t = -b - sqrt(disc);
+    // Most (wave, sphere) pairs have no lane with a positive discriminant: skip the square root
+    // for the whole wave then.
+    if (__builtin_amdgcn_ballot_w64(disc > 0.0) != 0) {
+        if (disc > 0.0) t = -b - sqrt(disc);
+    }
     return t;
 }
 
+// Plane whose stored normal is exactly +-e_k.  With n = s*e_k the reference's two dot products
+// are exactly s*d_k and s*(c_k - o_k) (the other terms are signed zeros), and their quotient is
+// (c_k - o_k) / d_k bit for bit whenever it is non-zero; zero or negative results never win the
+// scan.  Valid for finite rays.
+PTD_INLINE double intersect_plane_axis(double ck, double ok, double dk) {
+    double t = (ck - ok) / dk;
+    return ((dk > -0.00001) && (dk < 0.00001)) ? -1.0 : t;
+}
+
+// Exact Shape::intersect value, signed zeros included (diagnostics).
 PTD_INLINE double intersect_body(const DGeom& g, V3 o, V3 d) {
-    return g.shape == kPlane ? intersect_plane(g, o, d) : intersect_sphere(g, o, d);
+    return g.shape == kSphere ? intersect_sphere(g, o, d) : intersect_plane(g, o, d);
+}
+
+// What the nearest-hit scan evaluates: equal to intersect_body wherever t > 0.
+PTD_INLINE double intersect_for_scan(const DGeom& g, V3 o, V3 d) {
+    switch (g.shape) {  // wave-uniform
+        case kSphere: return intersect_sphere(g, o, d);
+        case kPlaneX: return intersect_plane_axis(g.cx, o.x, d.x);
+        case kPlaneY: return intersect_plane_axis(g.cy, o.y, d.y);
+        case kPlaneZ: return intersect_plane_axis(g.cz, o.z, d.z);
+        default: return intersect_plane(g, o, d);
+    }
 }
 
 // Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint), ties to the larger index;
@@ -170,7 +205,7 @@ PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, in
     double mint = 1.7976931348623157e308;  // DBL_MAX
     for (int i = 0; i < n; ++i) {
         DGeom g = geom[i];
-        double t = intersect_body(g, o, d);
+        double t = intersect_for_scan(g, o, d);
         bool take = (t > 0.0) && (t <= mint) && (i != skip);
         mint = take ? t : mint;
         hit = take ? i : hit;
@@ -182,13 +217,26 @@ PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, in
 // ---- materials -------------------------------------------------------------------------
 // getRandomNormalInHemisphere main.cpp:105-117.  Draw order z, y, x (g++ evaluates the
 // constructor arguments right to left); the normalised copy is discarded by the reference.
+// The rejection test dot(v,v) > 1.0 is first screened in float: a candidate whose float length
+// is outside 1 +- 1e-5 is decided without forming the doubles (the float evaluation is within
+// 2.5e-6 of the exact value); only candidates inside that shell take the exact FP64 test.  The
+// accepted triple is then converted once.  Decisions and results are identical to the plain loop.
 PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
-    V3 v;
-    do {
-        v.z = unif_pm1(dr);
-        v.y = unif_pm1(dr);
-        v.x = unif_pm1(dr);
-    } while (dot(v, v) > 1.0);
+    int32_t kz, ky, kx;
+    for (;;) {
+        kz = rng_next(dr.rng);
+        ky = rng_next(dr.rng);
+        kx = rng_next(dr.rng);
+        dr.count += 3;
+        const float sc = 2.0f / 2147483647.0f;
+        float fz = (float)kz * sc - 1.0f, fy = (float)ky * sc - 1.0f, fx = (float)kx * sc - 1.0f;
+        float s2 = fx * fx + fy * fy + fz * fz;
+        if (s2 > 1.00001f) continue;
+        if (s2 < 0.99999f) break;
+        V3 e = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
+        if (!(dot(e, e) > 1.0)) break;
+    }
+    V3 v = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
     if (dot(v, n) < 0.0) v = muls(v, -1.0);
     return v;
 }
@@ -225,7 +273,7 @@ PTD_INLINE V3 bounce(const DMat& m, Draws& dr, V3 d, V3 n) {
 
 // getNormal: Plane main.cpp:192-194, Sphere main.cpp:224-226
 PTD_INLINE V3 shape_normal(const DGeom& g, V3 point) {
-    if (g.shape == kPlane) return mk(g.nx, g.ny, g.nz);
+    if (g.shape != kSphere) return mk(g.nx, g.ny, g.nz);
     return normalize(sub(point, mk(g.cx, g.cy, g.cz)));
 }
 

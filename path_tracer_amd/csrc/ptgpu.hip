@@ -2,8 +2,9 @@
 //
 // Render pipeline for one batch of B iterations:
 //   k_frame_layout : per iteration, the jitter tables of Renderer::iterate (main.cpp:352-357):
-//                    y per row, x per pixel (running sums, exactly as the reference's loops
-//                    accumulate them), row lengths and the running-index row starts.
+//                    y per row, x at every 32nd pixel of a row (running sums, exactly as the
+//                    reference's loops accumulate them; k_trace continues the sum from the nearest
+//                    checkpoint), row lengths and the running-index row starts.
 //   k_trace<EST>   : one thread per (destination pixel, iteration): camera ray, <=5 segments of
 //                    nearest-hit scan + bounce, then (NEE) light pick, <=5 shadow scans and the
 //                    backward colour recurrence.  Writes one FP64 RGB sample.
@@ -42,6 +43,7 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 constexpr int kBlock = 256;
+constexpr int kXStride = 32;  // the x running sum of a row is stored at every 32nd column
 
 struct Partition {
     int rank, world;
@@ -77,7 +79,8 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
     const int chunk = (H + nthr - 1) / nthr;
     const int r0 = tid * chunk;
     const int r1 = min(H, r0 + chunk);
-    double* xs_b = xs + (size_t)b * H * W;
+    const int CK = (W + kXStride - 1) / kXStride;
+    double* xs_b = xs + (size_t)b * H * CK;
     double* ys_b = ys + (size_t)b * H;
     int32_t* rs_b = row_start + (size_t)b * (H + 1);
 
@@ -100,9 +103,9 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
         if (r < nrows) {
             Rng j = rng_init(seed, it, kDomRow, (uint32_t)r);
             double x = k_to_unit(rng_next(j)) / (double)W;
-            double* row = xs_b + (size_t)r * W;
+            double* row = xs_b + (size_t)r * CK;
             while (x < 0.99999 && len < W) {
-                row[len] = x;
+                if ((len & (kXStride - 1)) == 0) row[len / kXStride] = x;
                 len++;
                 x += xstep;
             }
@@ -133,8 +136,8 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 template <int EST, bool MEASURED>
 __global__ void __launch_bounds__(kBlock) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
-                                                  const int32_t* __restrict__ npix, double* __restrict__ samples,
-                                                  size_t sample_stride) {
+                                                  const int32_t* __restrict__ npix, double xstep,
+                                                  double* __restrict__ samples, size_t sample_stride) {
     __shared__ double s_pts[kMaxDepth * 3 * kBlock];
     __shared__ int32_t s_bod[kMaxDepth * kBlock];
     const int tid = threadIdx.x;
@@ -149,7 +152,11 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene S, Partition P, int fir
         int r = slot / W;
         while (slot >= rs[r + 1]) r++;
         int c = slot - rs[r];
-        double x = xs[((size_t)b * H + r) * W + c];
+        // x of column c: the row's running sum x += xstep (main.cpp:355-357), continued from the
+        // stored value at the previous multiple of 32
+        const int CK = (W + kXStride - 1) / kXStride;
+        double x = xs[((size_t)b * H + r) * CK + c / kXStride];
+        for (int i = c & (kXStride - 1); i > 0; --i) x += xstep;
         double y = ys[(size_t)b * H + r];
         Draws dr;
         dr.rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
@@ -357,7 +364,7 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
 int ensure_render_buffers(pt_scene* s) {
     const size_t W = s->width, H = s->height, B = s->batch;
     int rc;
-    if ((rc = s->d_xs.ensure(B * H * W * sizeof(double)))) return rc;
+    if ((rc = s->d_xs.ensure(B * H * ((W + kXStride - 1) / kXStride) * sizeof(double)))) return rc;
     if ((rc = s->d_ys.ensure(B * H * sizeof(double)))) return rc;
     if ((rc = s->d_rowstart.ensure(B * (H + 1) * sizeof(int32_t)))) return rc;
     if ((rc = s->d_npix.ensure(B * sizeof(int32_t)))) return rc;
@@ -382,6 +389,11 @@ int upload_scene(pt_scene* s) {
             g.nx = b.normal[0];
             g.ny = b.normal[1];
             g.nz = b.normal[2];
+            // axis-aligned unit normals take the one-division form of the scan
+            auto unit = [](double v) { return v == 1.0 || v == -1.0; };
+            if (unit(g.nx) && g.ny == 0.0 && g.nz == 0.0) g.shape = kPlaneX;
+            if (g.nx == 0.0 && unit(g.ny) && g.nz == 0.0) g.shape = kPlaneY;
+            if (g.nx == 0.0 && g.ny == 0.0 && unit(g.nz)) g.shape = kPlaneZ;
         } else {
             g.nx = b.radius * b.radius;  // Sphere ctor radius2 main.cpp:207
         }
@@ -601,11 +613,11 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         HIP_TRY(hipEventRecord(s->ev[s->ev_used], st));
         dim3 grid(P.owned_tiles, B);
         if (s->estimator == PT_EST_NEE && s->has_measured)
-            hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, samples, J);
+            hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
         else if (s->estimator == PT_EST_NEE)
-            hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, samples, J);
+            hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
         else
-            hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, samples, J);
+            hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
         HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], st));
         s->ev_used += 2;
         hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, st, P, W, H, B, npix, samples, J, accum_dev);
@@ -736,19 +748,25 @@ int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t*
     if (rc) return rc;
     const int W = s->width, H = s->height;
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
-    HIP_TRY(hipMemset(s->d_xs.p, 0xFF, sizeof(double) * (size_t)W * H));
-    HIP_TRY(hipMemset(s->d_ys.p, 0xFF, sizeof(double) * (size_t)H));
+    const int CK = (W + kXStride - 1) / kXStride;
     hipLaunchKernelGGL(k_frame_layout, dim3(1), dim3(layout_threads), 0, 0, s->seed, W, H, iteration, s->xstep, s->ystep,
                        (double*)s->d_xs.p, (double*)s->d_ys.p, (int32_t*)s->d_rowstart.p, (int32_t*)s->d_npix.p);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> rs(H + 1);
-    HIP_TRY(hipMemcpy(xs, s->d_xs.p, sizeof(double) * (size_t)W * H, hipMemcpyDeviceToHost));
+    std::vector<double> ck((size_t)H * CK);
+    HIP_TRY(hipMemcpy(ck.data(), s->d_xs.p, sizeof(double) * ck.size(), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ys, s->d_ys.p, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(rs.data(), s->d_rowstart.p, sizeof(int32_t) * (H + 1), hipMemcpyDeviceToHost));
     int nr = 0;
     for (int r = 0; r < H; ++r) {
         row_len[r] = rs[r + 1] - rs[r];
         if (row_len[r] > 0) nr = r + 1;
+        // expand the checkpoints the way k_trace does: continue the running sum (IEEE double adds)
+        for (int c = 0; c < row_len[r]; ++c) {
+            volatile double x = ck[(size_t)r * CK + c / kXStride];
+            for (int i = c & (kXStride - 1); i > 0; --i) x = x + s->xstep;
+            xs[(size_t)r * W + c] = x;
+        }
     }
     *nrows = nr;
     return PT_OK;
