@@ -119,9 +119,10 @@ struct DMat {  // 96 bytes
     double colr, colg, colb;
     double emr, emg, emb;
     double ior, refl;
+    double eta;  // 1.0 / ior (Glass::bounce main.cpp:291)
     int32_t material;
     int32_t brdf_id;
-    int32_t pad[6];
+    int32_t pad[4];
 };
 
 struct DScene {
@@ -164,49 +165,68 @@ PTD_INLINE double intersect_sphere(const DGeom& g, V3 o, V3 d) {
     double c = (dx * dx + dy * dy + dz * dz) - g.nx;
     double disc = (b * b) - c;
     double t = -1.0;
-    // Most (wave, sphere) pairs have no lane with a positive discriminant: skip the square root
-    // for the whole wave then.
-    if (__builtin_amdgcn_ballot_w64(disc > 0.0) != 0) {
-        if (disc > 0.0) t = -b - sqrt(disc);
-    }
+    if (disc > 0.0) t = -b - sqrt(disc);
     return t;
 }
 
-// Plane whose stored normal is exactly +-e_k.  With n = s*e_k the reference's two dot products
-// are exactly s*d_k and s*(c_k - o_k) (the other terms are signed zeros), and their quotient is
-// (c_k - o_k) / d_k bit for bit whenever it is non-zero; zero or negative results never win the
-// scan.  Valid for finite rays.
-PTD_INLINE double intersect_plane_axis(double ck, double ok, double dk) {
-    double t = (ck - ok) / dk;
-    return ((dk > -0.00001) && (dk < 0.00001)) ? -1.0 : t;
-}
+// Planes whose stored normal is exactly +-e_k take a one-division form in the scan: with
+// n = s*e_k the reference's two dot products are exactly s*d_k and s*(c_k - o_k) (the other terms
+// are signed zeros), and their quotient is (c_k - o_k) / d_k bit for bit whenever it is non-zero;
+// zero or negative results never win the scan.  Valid for finite rays.
 
 // Exact Shape::intersect value, signed zeros included (diagnostics).
 PTD_INLINE double intersect_body(const DGeom& g, V3 o, V3 d) {
     return g.shape == kSphere ? intersect_sphere(g, o, d) : intersect_plane(g, o, d);
 }
 
-// What the nearest-hit scan evaluates: equal to intersect_body wherever t > 0.
-PTD_INLINE double intersect_for_scan(const DGeom& g, V3 o, V3 d) {
-    switch (g.shape) {  // wave-uniform
-        case kSphere: return intersect_sphere(g, o, d);
-        case kPlaneX: return intersect_plane_axis(g.cx, o.x, d.x);
-        case kPlaneY: return intersect_plane_axis(g.cy, o.y, d.y);
-        case kPlaneZ: return intersect_plane_axis(g.cz, o.z, d.z);
-        default: return intersect_plane(g, o, d);
+// The scan's view of Shape::intersect: `t` plus a flag that is false where the reference returns
+// -1 (parallel plane, sphere without a positive discriminant) — a value that can never pass
+// (t > 0).  Carrying the flag instead of the -1 saves the 64-bit selects.
+PTD_INLINE bool scan_plane(const DGeom& g, V3 o, V3 d, double& t) {
+    double n_dot_u = g.nx * d.x + g.ny * d.y + g.nz * d.z;
+    double n_dot_p0 = g.nx * (g.cx - o.x) + g.ny * (g.cy - o.y) + g.nz * (g.cz - o.z);
+    t = n_dot_p0 / n_dot_u;
+    return !((n_dot_u > -0.00001) && (n_dot_u < 0.00001));
+}
+PTD_INLINE bool scan_plane_axis(double ck, double ok, double dk, double& t) {
+    t = (ck - ok) / dk;
+    return !((dk > -0.00001) && (dk < 0.00001));
+}
+PTD_INLINE bool scan_sphere(const DGeom& g, V3 o, V3 d, double& t) {
+    double dx = o.x - g.cx, dy = o.y - g.cy, dz = o.z - g.cz;
+    double b = dx * d.x + dy * d.y + dz * d.z;
+    double c = (dx * dx + dy * dy + dz * dz) - g.nx;
+    double disc = (b * b) - c;
+    // -b - sqrt(disc) can only be positive when b < 0; most (wave, sphere) pairs have no such lane
+    // and skip the square root altogether.
+    bool ok = (disc > 0.0) && (b < 0.0);
+    t = 0.0;
+    if (__builtin_amdgcn_ballot_w64(ok) != 0) {
+        double dd = disc;
+        asm volatile("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
+        t = -b - sqrt(dd);
     }
+    return ok;
 }
 
 // Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint), ties to the larger index;
 // `skip` is the light excluded by next_event.cpp:415-419 (-1: none).  Body records are read at
-// wave-uniform addresses.
+// wave-uniform addresses (scalar loads); the shape switch is a scalar branch.
 PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     for (int i = 0; i < n; ++i) {
         DGeom g = geom[i];
-        double t = intersect_for_scan(g, o, d);
-        bool take = (t > 0.0) && (t <= mint) && (i != skip);
+        double t;
+        bool ok;
+        switch (g.shape) {
+            case kSphere: ok = scan_sphere(g, o, d, t); break;
+            case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
+            case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
+            case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
+            default: ok = scan_plane(g, o, d, t); break;
+        }
+        bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
         mint = take ? t : mint;
         hit = take ? i : hit;
     }
@@ -249,14 +269,11 @@ PTD_INLINE V3 bounce_chrome(V3 d, V3 n) {
 
 // Glass::bounce main.cpp:279-305.  theta1 = fabs(..) >= 0 always, so internal = ior,
 // external = 1.  theta2 is an x87 extended-precision expression (ptx::x87_glass_theta2).
-PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double refl) {
+PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double eta, double refl) {
     double theta1 = fabs(dot(d, n));
-    double internalIndex = ior, externalIndex = 1.0;
-    if (!(theta1 >= 0.0)) {  // NaN only
-        internalIndex = 1.0;
-        externalIndex = ior;
-    }
-    double eta = externalIndex / internalIndex;
+    // eta = externalIndex / internalIndex = 1.0 / ior, divided once on the host.  (A NaN theta1 would
+    // take the reference's other branch; every output is NaN either way.)
+    const double internalIndex = ior, externalIndex = 1.0;
     double theta2 = ptx::x87_glass_theta2(eta, theta1);
     double rs = (externalIndex * theta1 - internalIndex * theta2) / (externalIndex * theta1 + internalIndex * theta2);
     double rp = (internalIndex * theta1 - externalIndex * theta2) / (internalIndex * theta1 + externalIndex * theta2);
@@ -267,7 +284,7 @@ PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double refl) {
 
 PTD_INLINE V3 bounce(const DMat& m, Draws& dr, V3 d, V3 n) {
     if (m.material == kChrome) return bounce_chrome(d, n);
-    if (m.material == kGlass) return bounce_glass(dr, d, n, m.ior, m.refl);
+    if (m.material == kGlass) return bounce_glass(dr, d, n, m.ior, m.eta, m.refl);
     return random_in_hemisphere(dr, n);  // Material::bounce main.cpp:250-253
 }
 
@@ -412,7 +429,7 @@ struct PathResult {
 //  PT : Renderer::trace main.cpp:367-405 — the recursion `trace(next)*color + emission` is a Horner
 //       evaluation from the deepest hit outwards.
 //  NEE: pixel body of Renderer::iterate next_event.cpp:384-470 with trace() next_event.cpp:491-530.
-template <int EST, bool MEASURED>
+template <int EST, bool MEASURED, bool ELIDE>
 PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y, const Records& rec) {
     const DGeom* __restrict__ geom = S.geom;
     const DMat* __restrict__ mat = S.mat;
@@ -431,7 +448,8 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         V3 normal = shape_normal(g, point);
         V3 dir = bounce(m, dr, d, normal);
         // main.cpp:394-401 (the comparison is against the float 0.0f)
-        double tt = (dot(dir, d) > 0.0) ? ptx::x87_mul_1p0000001(mint) : ptx::x87_mul_0p9999999(mint);
+        bool fwd = dot(dir, d) > 0.0;
+        double tt = ptx::x87_mul_const(mint, fwd ? 0x1.000001ad7f29bp+0 : 0x1.fffffca501acbp-1, fwd ? -0x1.0d8p-54 : -0x1.e58p-55);
         point = add(o, muls(d, tt));
         rec.put(n, point, hit);
         o = point;
@@ -470,6 +488,11 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         lc = mk(lg.cx, lg.cy, lg.cz);
     }
     V3 lterm = mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
+    // When emission*colour of the chosen light is exactly zero (every light of the reference's own
+    // scenes has colour 0, next_event.cpp:660,674), (Le*Lc)*flux is a zero of known sign whatever
+    // the finite flux is, and nothing after this loop reads the random stream: the fake-BRDF
+    // bounce that produces flux is dead and ELIDE skips it.  Results are bit-identical.
+    const bool direct_is_zero = (lterm.x == 0.0) && (lterm.y == 0.0) && (lterm.z == 0.0);
 #pragma unroll 1
     for (int gi = n - 1; gi >= 0; --gi) {
         V3 P = rec.point(gi);
@@ -481,10 +504,16 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         R.visible |= 1 << gi;
         DGeom g = geom[hit];
         DMat m = mat[hit];
+        V3 scale;
+        // flux is finite for diffuse and chrome, and for glass with ior >= 1
+        if (ELIDE && direct_is_zero && m.material != kMeasured && (m.material != kGlass || m.ior >= 1.0)) {
+            scale = muls(lterm, 0.0);
+            L = add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+            continue;
+        }
         V3 next_point = campt;
         if (gi >= 1) next_point = rec.point(gi - 1);
         V3 nprime = normalize(sub(next_point, P));
-        V3 scale;
         if (MEASURED && m.material == kMeasured) {
             // Defined by this build: the table RGB replaces the scalar flux (the reference's own
             // lookups, raytrace3.cpp:646-676, are never executed).

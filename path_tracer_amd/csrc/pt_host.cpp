@@ -210,6 +210,16 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
     } else if (s == "pt15") {  // main.cpp's estimator on the 15-body / 2-light scene (bipath.cpp:556-558)
         desc->estimator = PT_EST_PT;
         scene_nee15(B);
+    } else if (s == "nee15_lit") {
+        // nee15 with light colour 1 instead of the reference's 0, so that the direct term
+        // (Le*Lc)*flux of next_event.cpp:462 is live (other programs of the reference light their
+        // scenes this way, e.g. raytrace3.cpp:967)
+        desc->estimator = PT_EST_NEE;
+        scene_nee15(B);
+        if (!B.overflow) {
+            Builder::set3(bodies[10].color, 1.0, 1.0, 1.0);
+            Builder::set3(bodies[14].color, 1.0, 1.0, 1.0);
+        }
     } else if (s == "nee15_measured") {
         // nee15 with the glass ball, the chrome ball, the floor and the back wall switched to
         // measured materials (tables 0..3); the two lights get colour 1 so that the direct

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene S, Partition P, int fir
         rec.bod = s_bod;
         rec.stride = kBlock;
         rec.tid = tid;
-        PathResult R = trace_path<EST, MEASURED>(S, dr, x, y, rec);
+        PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
         rgb = R.rgb;
     }
     out[0] = rgb.x;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_paths(DScene S, const int32_t*
     rec.bod = s_bod;
     rec.stride = kBlock;
     rec.tid = threadIdx.x;
-    PathResult R = trace_path<EST, MEASURED>(S, dr, xy[2 * i], xy[2 * i + 1], rec);
+    PathResult R = trace_path<EST, MEASURED, false>(S, dr, xy[2 * i], xy[2 * i + 1], rec);
     if (rgb) {
         rgb[3 * i] = R.rgb.x;
         rgb[3 * i + 1] = R.rgb.y;
@@ -408,6 +408,7 @@ int upload_scene(pt_scene* s) {
         m.emb = b.emission[2];
         m.ior = b.ior;
         m.refl = b.reflection;
+        m.eta = 1.0 / b.ior;
         m.material = b.material;
         m.brdf_id = b.brdf_id;
         mat[i] = m;

@@ -11,7 +11,7 @@ from _oracle import EST_NEE, EST_PT, MODE_PIXEL
 from conftest import GOLDEN, same_bits
 
 pytestmark = pytest.mark.gpu
-EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT}
+EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE}
 
 
 def oracle_scene(port, renderer, W, H, seed, flags=0, tables=None):
@@ -86,7 +86,7 @@ def test_frame_layout(port, W, H, seed):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["nee15", "main32", "pt15"])
+@pytest.mark.parametrize("name", ["nee15", "main32", "pt15", "nee15_lit"])
 def test_paths_match_oracle(port, name):
     rng = np.random.default_rng(11)
     n = 20000
@@ -99,7 +99,7 @@ def test_paths_match_oracle(port, name):
     assert np.array_equal(g["nrec"], o["nrec"])
     assert np.array_equal(g["bodies"], o["bodies"])
     assert np.array_equal(g["draws"], o["draws"])
-    if name == "nee15":
+    if name.startswith("nee15"):
         assert np.array_equal(g["visible"], o["visible"])
     # offset points: the oracle mirrors the reference's x87 islands, the GPU is plain FP64
     np.testing.assert_allclose(g["points"], o["points"], rtol=1e-12, atol=1e-13)
@@ -119,7 +119,8 @@ def test_golden_frames(port):
         r.close()
 
 
-@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40)])
+@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40),
+                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4)])
 def test_frames_match_oracle(port, name, W, H, n_it):
     r = pt.Renderer(pt.preset(name, W, H, seed=2025))
     s = oracle_scene(port, r, W, H, 2025)
