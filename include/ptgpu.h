@@ -110,6 +110,14 @@ int pt_brdf_load_file(pt_scene* scene, int brdf_id, const char* path);
  * (main.cpp:436-458, 642-645). */
 int pt_set_partition(pt_scene* scene, int rank, int world, int tile_w, int tile_h);
 
+/* Two device pipelines compute the same estimator with identical results.  FUSED: one kernel per
+ * batch, path state in registers/LDS, body list read through the scalar cache (up to 127 bodies).
+ * WAVEFRONT: one kernel per stage over compacted queues of live paths, path state in HBM, body
+ * list staged through LDS in tiles (any body count).  AUTO picks FUSED when it applies.
+ * No counterpart in the reference (its trace() is one recursive function, main.cpp:367-405). */
+enum { PT_PIPELINE_AUTO = 0, PT_PIPELINE_FUSED = 1, PT_PIPELINE_WAVEFRONT = 2 };
+int pt_set_pipeline(pt_scene* scene, int pipeline);
+
 /* Replaces `for (i < iterations) renderer.iterate()` (main.cpp:439-442, 349-365): adds
  * iterations [first_iteration, first_iteration + n_iterations) into accum (host memory).
  * Samples of one pixel are added in iteration order, so the result does not depend on how a

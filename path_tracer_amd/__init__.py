@@ -20,6 +20,7 @@ EST_PT, EST_NEE = 0, 1
 F_LIGHT_TRUE_CENTER = 1
 BRDF_TABLE_DOUBLES = 3 * 90 * 90 * 180
 DOM_PIXEL, DOM_ROW, DOM_FRAME, DOM_SEQ = 0, 1, 2, 3
+PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 
 
 class PtError(RuntimeError):
@@ -200,6 +201,9 @@ class Renderer:
 
     def set_partition(self, rank, world, tile_w=32, tile_h=8):
         _check(lib().pt_set_partition(self._h, rank, world, tile_w, tile_h))
+
+    def set_pipeline(self, pipeline):
+        _check(lib().pt_set_pipeline(self._h, int(pipeline)))
 
     def stats(self):
         st = Stats()

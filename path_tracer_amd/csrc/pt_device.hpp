@@ -404,14 +404,14 @@ PTD_INLINE void vector_to_spherical(V3 in, double& theta, double& phi) {
 // pts[(k*3 + c) * stride + tid], its body at bod[k * stride + tid].
 struct Records {
     double* pts;
-    int32_t* bod;
+    int8_t* bod;  // the fused kernels handle at most 127 bodies
     int stride;
     int tid;
     PTD_INLINE void put(int k, V3 p, int body) const {
         pts[(k * 3 + 0) * stride + tid] = p.x;
         pts[(k * 3 + 1) * stride + tid] = p.y;
         pts[(k * 3 + 2) * stride + tid] = p.z;
-        bod[k * stride + tid] = body;
+        bod[k * stride + tid] = (int8_t)body;
     }
     PTD_INLINE V3 point(int k) const {
         return mk(pts[(k * 3 + 0) * stride + tid], pts[(k * 3 + 1) * stride + tid], pts[(k * 3 + 2) * stride + tid]);
@@ -429,6 +429,95 @@ struct PathResult {
 //  PT : Renderer::trace main.cpp:367-405 — the recursion `trace(next)*color + emission` is a Horner
 //       evaluation from the deepest hit outwards.
 //  NEE: pixel body of Renderer::iterate next_event.cpp:384-470 with trace() next_event.cpp:491-530.
+// ---- stages shared by the fused kernel and the wavefront pipeline -------------------------
+
+// One trace() level after the scan (main.cpp:391-403 / next_event.cpp:515-528): hit point, normal,
+// bounce, then the hit point moved by the factor 1 +- 1e-7 along the ray.  Updates the ray in
+// place and returns the recorded (offset) point.
+PTD_INLINE V3 shade_hit(const DGeom& g, const DMat& m, Draws& dr, V3& o, V3& d, double mint) {
+    V3 point = add(o, muls(d, mint));
+    V3 normal = shape_normal(g, point);
+    V3 dir = bounce(m, dr, d, normal);
+    // main.cpp:394-401 (the comparison is against the float 0.0f)
+    bool fwd = dot(dir, d) > 0.0;
+    double tt = ptx::x87_mul_const(mint, fwd ? 0x1.000001ad7f29bp+0 : 0x1.fffffca501acbp-1,
+                                   fwd ? -0x1.0d8p-54 : -0x1.e58p-55);
+    point = add(o, muls(d, tt));
+    o = point;
+    d = dir;
+    return point;
+}
+
+// lights[unifRand(lights.size() - 1)] next_event.cpp:390; unifRand(long) main.cpp:36-47.
+// Returns the body index of the chosen light (lights[0] is never chosen when there are several).
+PTD_INLINE int pick_light(const DScene& S, Draws& dr) {
+    int li = 0;
+    int nl = S.n_lights - 1;
+    if (nl < 0) nl = -nl;
+    if (nl != 0) {
+        long guard = (long)(unif(dr) * (double)nl) + 1;
+        li = guard > nl ? nl : (int)guard;
+    }
+    return S.lights[li];
+}
+
+struct LightTerm {
+    V3 lc;     // origin of the shadow rays
+    V3 lterm;  // emission * colour
+    bool direct_is_zero;
+};
+PTD_INLINE LightTerm light_term(const DScene& S, int light) {
+    LightTerm T;
+    DMat lm = S.mat[light];
+    // light->shape->center through a Shape* is the never-assigned base member (0,0,0)
+    // (next_event.cpp:167,406-407) unless the scene asks for the real centre.
+    T.lc = mk(0.0, 0.0, 0.0);
+    if (S.flags & 1u) {
+        DGeom lg = S.geom[light];
+        T.lc = mk(lg.cx, lg.cy, lg.cz);
+    }
+    T.lterm = mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
+    // When emission*colour of the chosen light is exactly zero (every light of the reference's own
+    // scenes has colour 0, next_event.cpp:660,674), (Le*Lc)*flux is a zero of known sign whatever
+    // the finite flux is, and nothing after the NEE loop reads the random stream: the fake-BRDF
+    // bounce that produces flux is dead and may be skipped.  Results are bit-identical.
+    T.direct_is_zero = (T.lterm.x == 0.0) && (T.lterm.y == 0.0) && (T.lterm.z == 0.0);
+    return T;
+}
+
+// One lit vertex of the NEE loop (next_event.cpp:442-463): L = ((L + (Le*Lc)*flux) * c) + e.
+// `bd` is the shadow-ray direction, `next_point` the previous vertex (or the camera-plane point
+// for vertex 0, next_event.cpp:443-447).
+template <bool MEASURED, bool ELIDE>
+PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& dr, const LightTerm& T, V3 P, V3 bd,
+                         V3 next_point, V3 L) {
+    V3 scale;
+    // flux is finite for diffuse and chrome, and for glass with ior >= 1
+    if (ELIDE && T.direct_is_zero && m.material != kMeasured && (m.material != kGlass || m.ior >= 1.0)) {
+        scale = muls(T.lterm, 0.0);
+        return add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+    }
+    V3 nprime = normalize(sub(next_point, P));
+    if (MEASURED && m.material == kMeasured) {
+        // Defined by this build: the table RGB replaces the scalar flux (the reference's own
+        // lookups, raytrace3.cpp:646-676, are never executed).
+        double ti, pi, to, po;
+        vector_to_spherical(bd, ti, pi);
+        vector_to_spherical(nprime, to, po);
+        V3 f = brdf_lookup(S.brdf[m.brdf_id], ti, pi, to, po, nullptr);
+        scale = mul(T.lterm, f);
+    } else {
+        V3 light_brdf = bounce(m, dr, bd, nprime);
+        double light_flux = fabs(dot(light_brdf, shape_normal(g, P)));
+        scale = muls(T.lterm, light_flux);
+    }
+    return add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+}
+
+// One (pixel, iteration) sample, all stages fused.
+//  PT : Renderer::trace main.cpp:367-405 — the recursion `trace(next)*color + emission` is a Horner
+//       evaluation from the deepest hit outwards.
+//  NEE: pixel body of Renderer::iterate next_event.cpp:384-470 with trace() next_event.cpp:491-530.
 template <int EST, bool MEASURED, bool ELIDE>
 PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y, const Records& rec) {
     const DGeom* __restrict__ geom = S.geom;
@@ -442,18 +531,8 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         double mint;
         int hit = nearest_hit(geom, S.n_bodies, o, d, -1, mint);
         if (hit < 0) break;
-        DGeom g = geom[hit];
-        DMat m = mat[hit];
-        V3 point = add(o, muls(d, mint));
-        V3 normal = shape_normal(g, point);
-        V3 dir = bounce(m, dr, d, normal);
-        // main.cpp:394-401 (the comparison is against the float 0.0f)
-        bool fwd = dot(dir, d) > 0.0;
-        double tt = ptx::x87_mul_const(mint, fwd ? 0x1.000001ad7f29bp+0 : 0x1.fffffca501acbp-1, fwd ? -0x1.0d8p-54 : -0x1.e58p-55);
-        point = add(o, muls(d, tt));
+        V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
         rec.put(n, point, hit);
-        o = point;
-        d = dir;
     }
     PathResult R;
     R.nrec = n;
@@ -468,67 +547,20 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         R.rgb = L;
         return R;
     }
-    // lights[unifRand(lights.size() - 1)] next_event.cpp:390; unifRand(long) main.cpp:36-47
-    int li = 0;
-    {
-        int nl = S.n_lights - 1;
-        if (nl < 0) nl = -nl;
-        if (nl != 0) {
-            long guard = (long)(unif(dr) * (double)nl) + 1;
-            li = guard > nl ? nl : (int)guard;
-        }
-    }
-    int light = S.lights[li];
-    DMat lm = mat[light];
-    // light->shape->center through a Shape* is the never-assigned base member (0,0,0)
-    // (next_event.cpp:167,406-407) unless the scene asks for the real centre.
-    V3 lc = mk(0.0, 0.0, 0.0);
-    if (S.flags & 1u) {
-        DGeom lg = geom[light];
-        lc = mk(lg.cx, lg.cy, lg.cz);
-    }
-    V3 lterm = mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
-    // When emission*colour of the chosen light is exactly zero (every light of the reference's own
-    // scenes has colour 0, next_event.cpp:660,674), (Le*Lc)*flux is a zero of known sign whatever
-    // the finite flux is, and nothing after this loop reads the random stream: the fake-BRDF
-    // bounce that produces flux is dead and ELIDE skips it.  Results are bit-identical.
-    const bool direct_is_zero = (lterm.x == 0.0) && (lterm.y == 0.0) && (lterm.z == 0.0);
+    int light = pick_light(S, dr);
+    LightTerm T = light_term(S, light);
 #pragma unroll 1
     for (int gi = n - 1; gi >= 0; --gi) {
         V3 P = rec.point(gi);
         int target = rec.body(gi);
-        V3 bd = normalize(sub(P, lc));
+        V3 bd = normalize(sub(P, T.lc));
         double mint;
-        int hit = nearest_hit(geom, S.n_bodies, lc, bd, light, mint);
-        if (hit != target) continue;
+        int hit = nearest_hit(geom, S.n_bodies, T.lc, bd, light, mint);
+        if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
-        DGeom g = geom[hit];
-        DMat m = mat[hit];
-        V3 scale;
-        // flux is finite for diffuse and chrome, and for glass with ior >= 1
-        if (ELIDE && direct_is_zero && m.material != kMeasured && (m.material != kGlass || m.ior >= 1.0)) {
-            scale = muls(lterm, 0.0);
-            L = add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
-            continue;
-        }
         V3 next_point = campt;
         if (gi >= 1) next_point = rec.point(gi - 1);
-        V3 nprime = normalize(sub(next_point, P));
-        if (MEASURED && m.material == kMeasured) {
-            // Defined by this build: the table RGB replaces the scalar flux (the reference's own
-            // lookups, raytrace3.cpp:646-676, are never executed).
-            double ti, pi, to, po;
-            vector_to_spherical(bd, ti, pi);
-            vector_to_spherical(nprime, to, po);
-            V3 f = brdf_lookup(S.brdf[m.brdf_id], ti, pi, to, po, nullptr);
-            scale = mul(lterm, f);
-        } else {
-            V3 light_brdf = bounce(m, dr, bd, nprime);
-            double light_flux = fabs(dot(light_brdf, shape_normal(g, P)));
-            scale = muls(lterm, light_flux);
-        }
-        // next_event.cpp:462-463
-        L = add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+        L = nee_vertex<MEASURED, ELIDE>(S, geom[hit], mat[hit], dr, T, P, bd, next_point, L);
     }
     R.rgb = L;
     return R;

@@ -1,0 +1,282 @@
+// Wavefront form of the estimator for scenes too large for the fused kernel: path state lives in
+// HBM (structure of arrays), each stage is its own kernel over a compacted queue of live paths,
+// and the nearest-hit scan stages the body list through LDS in tiles.
+//
+//   k_wf_generate        camera rays, per-path RNG streams, queue 0
+//   k_wf_extend<GATHER>  nearest hit of the current ray           (main.cpp:372-383)
+//   k_wf_shade           point / normal / bounce / offset / record (main.cpp:391-403), queue d+1
+//   k_wf_light           light pick                                (next_event.cpp:390)
+//   k_wf_extend<SHADOW>  nearest hit of the shadow ray, light excluded (next_event.cpp:405-426)
+//   k_wf_nee             visibility test + colour recurrence      (next_event.cpp:428-463)
+//   k_wf_finish          Horner (PT) / store the sample
+//
+// A path that leaves the scene is not pushed to the next queue, so later stages run on dense
+// waves only (wave64 ballot + one atomic per wave).  Queue d+1 holds the paths with more than d
+// recorded vertices; the NEE stages reuse those queues deepest first.  The arithmetic of every
+// stage is the same device code the fused kernel uses, so both pipelines give identical bits.
+#pragma once
+#include "pt_device.hpp"
+
+namespace ptw {
+
+using namespace ptd;
+
+constexpr int kWfBlock = 256;
+constexpr int kTileBodies = 512;  // 512 x 64 B = 32 KiB of LDS per block
+
+struct WfState {
+    double* ray;     // [6][cap]  origin xyz, direction xyz
+    double* xy;      // [2][cap]  image-plane coordinates of the sample
+    double* pts;     // [15][cap] recorded offset points, (vertex*3 + component)
+    double* L;       // [3][cap]  running colour
+    double* t;       // [cap]     distance of the last scan
+    uint32_t* rng;   // [4][cap]
+    int32_t* hit;    // [cap]     body of the last scan
+    int32_t* bod;    // [5][cap]  recorded bodies
+    int32_t* nrec;   // [cap]
+    int32_t* light;  // [cap]
+    int32_t* queue;  // [6][cap]
+    int32_t* qcount; // [8]
+    size_t cap;
+};
+
+// Append `value` for every lane with `pred` set; one atomic per wave.  Call with the whole wave.
+PTD_INLINE void queue_push(int32_t* q, int32_t* count, bool pred, int value) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    if (m == 0) return;
+    const int lane = __lane_id();
+    const int leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, (int)__builtin_popcountll(m));
+    base = __shfl(base, leader);
+    if (pred) q[base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+PTD_INLINE Rng load_rng(const WfState& W, size_t p) {
+    Rng r;
+    r.s0 = W.rng[p];
+    r.s1 = W.rng[W.cap + p];
+    r.s2 = W.rng[2 * W.cap + p];
+    r.s3 = W.rng[3 * W.cap + p];
+    return r;
+}
+PTD_INLINE void store_rng(const WfState& W, size_t p, const Rng& r) {
+    W.rng[p] = r.s0;
+    W.rng[W.cap + p] = r.s1;
+    W.rng[2 * W.cap + p] = r.s2;
+    W.rng[3 * W.cap + p] = r.s3;
+}
+PTD_INLINE V3 load3(const double* a, size_t cap, size_t p, int first) {
+    return mk(a[(size_t)first * cap + p], a[(size_t)(first + 1) * cap + p], a[(size_t)(first + 2) * cap + p]);
+}
+PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
+    a[(size_t)first * cap + p] = v.x;
+    a[(size_t)(first + 1) * cap + p] = v.y;
+    a[(size_t)(first + 2) * cap + p] = v.z;
+}
+
+// Nearest-hit scan with the body list staged through LDS in tiles of kTileBodies records.
+// Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
+// Same acceptance rule and body order as ptd::nearest_hit.
+PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, bool active,
+                                 DGeom* s_tile, double& tmin) {
+    int hit = -1;
+    double mint = 1.7976931348623157e308;  // DBL_MAX
+    for (int base = 0; base < n; base += kTileBodies) {
+        const int cnt = min(kTileBodies, n - base);
+        __syncthreads();  // the previous tile has been consumed by every wave
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(geom + base);
+            uint4* dst = reinterpret_cast<uint4*>(s_tile);
+            for (int k = threadIdx.x; k < cnt * 4; k += blockDim.x) dst[k] = src[k];  // 16 B per lane, coalesced
+        }
+        __syncthreads();
+        if (active) {
+            for (int i = 0; i < cnt; ++i) {
+                DGeom g = s_tile[i];  // same address in every lane: LDS broadcast
+                const int shape = __builtin_amdgcn_readfirstlane(g.shape);
+                double t;
+                bool ok;
+                switch (shape) {
+                    case kSphere: ok = scan_sphere(g, o, d, t); break;
+                    case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
+                    case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
+                    case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
+                    default: ok = scan_plane(g, o, d, t); break;
+                }
+                const int idx = base + i;
+                bool take = ok && (t > 0.0) && (t <= mint) && (idx != skip);
+                mint = take ? t : mint;
+                hit = take ? idx : hit;
+            }
+        }
+    }
+    tmin = mint;
+    return hit;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------
+
+// grid (owned tiles, iterations of the batch); path id = b * J + j with j = tile * 256 + tid.
+template <class PartitionT, class SlotFn>
+__device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, SlotFn slot_of_fn, int first_it,
+                                        const double* __restrict__ xs, const double* __restrict__ ys,
+                                        const int32_t* __restrict__ row_start, const int32_t* __restrict__ npix,
+                                        double xstep, int xstride, WfState W, size_t J) {
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int Wd = S.width, H = S.height;
+    const int slot = slot_of_fn(P, blockIdx.x, tid, Wd, H);
+    const size_t p = (size_t)b * J + (size_t)blockIdx.x * kWfBlock + tid;
+    const bool valid = slot >= 0 && slot < npix[b];
+    if (valid) {
+        const int32_t* rs = row_start + (size_t)b * (H + 1);
+        int r = slot / Wd;
+        while (slot >= rs[r + 1]) r++;
+        int c = slot - rs[r];
+        const int CK = (Wd + xstride - 1) / xstride;
+        double x = xs[((size_t)b * H + r) * CK + c / xstride];
+        for (int i = c % xstride; i > 0; --i) x += xstep;
+        double y = ys[(size_t)b * H + r];
+        V3 o = ld3(S.cam_o);
+        V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157
+        store3(W.ray, W.cap, p, 0, o);
+        store3(W.ray, W.cap, p, 3, d);
+        W.xy[p] = x;
+        W.xy[W.cap + p] = y;
+        store_rng(W, p, rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot));
+        W.nrec[p] = 0;
+        store3(W.L, W.cap, p, 0, mk(0.0, 0.0, 0.0));
+    }
+    queue_push(W.queue, W.qcount, valid, (int)p);
+}
+
+enum { kGather = 0, kShadow = 1 };
+
+// One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.
+template <int MODE>
+__global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int qi, int gi) {
+    __shared__ DGeom s_tile[kTileBodies];
+    const int count = W.qcount[qi];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if ((int)(blockIdx.x * kWfBlock) >= count) return;  // whole block idle
+    const bool active = i < count;
+    size_t p = 0;
+    V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 1.0);
+    int skip = -1;
+    if (active) {
+        p = (size_t)W.queue[(size_t)qi * W.cap + i];
+        if (MODE == kGather) {
+            o = load3(W.ray, W.cap, p, 0);
+            d = load3(W.ray, W.cap, p, 3);
+        } else {
+            const int light = W.light[p];
+            LightTerm T = light_term(S, light);
+            V3 Pt = load3(W.pts, W.cap, p, gi * 3);
+            o = T.lc;
+            d = normalize(sub(Pt, T.lc));  // next_event.cpp:405-407
+            skip = light;
+        }
+    }
+    double mint;
+    int hit = nearest_hit_tiled(S.geom, S.n_bodies, o, d, skip, active, s_tile, mint);
+    if (active) {
+        W.hit[p] = hit;
+        W.t[p] = mint;
+    }
+}
+
+// Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.
+__global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int qi, int depth) {
+    const int count = W.qcount[qi];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if ((int)(blockIdx.x * kWfBlock) >= count) return;
+    bool alive = false;
+    size_t p = 0;
+    if (i < count) {
+        p = (size_t)W.queue[(size_t)qi * W.cap + i];
+        const int hit = W.hit[p];
+        if (hit >= 0) {
+            alive = true;
+            V3 o = load3(W.ray, W.cap, p, 0), d = load3(W.ray, W.cap, p, 3);
+            Draws dr;
+            dr.rng = load_rng(W, p);
+            dr.count = 0;
+            V3 point = shade_hit(S.geom[hit], S.mat[hit], dr, o, d, W.t[p]);
+            store3(W.pts, W.cap, p, depth * 3, point);
+            W.bod[(size_t)depth * W.cap + p] = hit;
+            W.nrec[p] = depth + 1;
+            store3(W.ray, W.cap, p, 0, o);
+            store3(W.ray, W.cap, p, 3, d);
+            store_rng(W, p, dr.rng);
+        }
+    }
+    queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p);
+}
+
+// Light pick for every generated path (queue 0), next_event.cpp:390.
+__global__ void __launch_bounds__(kWfBlock) k_wf_light(DScene S, WfState W) {
+    const int count = W.qcount[0];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if (i >= count) return;
+    const size_t p = (size_t)W.queue[i];
+    Draws dr;
+    dr.rng = load_rng(W, p);
+    dr.count = 0;
+    W.light[p] = pick_light(S, dr);
+    store_rng(W, p, dr.rng);
+}
+
+// NEE vertex gi for the paths of queue gi + 1 (those with more than gi records).
+template <bool MEASURED, bool ELIDE>
+__global__ void __launch_bounds__(kWfBlock, MEASURED ? 2 : 4) k_wf_nee(DScene S, WfState W, int gi) {
+    const int count = W.qcount[gi + 1];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if (i >= count) return;
+    const size_t p = (size_t)W.queue[(size_t)(gi + 1) * W.cap + i];
+    const int hit = W.hit[p];
+    if (hit != W.bod[(size_t)gi * W.cap + p]) return;  // occluded: vertex skipped, next_event.cpp:428-430
+    const int light = W.light[p];
+    LightTerm T = light_term(S, light);
+    V3 Pt = load3(W.pts, W.cap, p, gi * 3);
+    V3 bd = normalize(sub(Pt, T.lc));
+    V3 next_point;
+    if (gi >= 1)
+        next_point = load3(W.pts, W.cap, p, (gi - 1) * 3);
+    else
+        next_point = cam_point(S, W.xy[p], W.xy[W.cap + p]);  // camera.getPoint(x, y) next_event.cpp:446
+    Draws dr;
+    dr.rng = load_rng(W, p);
+    dr.count = 0;
+    V3 L = load3(W.L, W.cap, p, 0);
+    L = nee_vertex<MEASURED, ELIDE>(S, S.geom[hit], S.mat[hit], dr, T, Pt, bd, next_point, L);
+    store3(W.L, W.cap, p, 0, L);
+    store_rng(W, p, dr.rng);
+}
+
+// Write the sample of every generated path: path id p = b * J + j -> samples[b][c][j].
+template <int EST>
+__global__ void __launch_bounds__(kWfBlock) k_wf_finish(DScene S, WfState W, double* __restrict__ samples, size_t J) {
+    const int count = W.qcount[0];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if (i >= count) return;
+    const size_t p = (size_t)W.queue[i];
+    V3 L;
+    if (EST == kEstPT) {
+        // trace(next)*color + emission, deepest hit first (main.cpp:404)
+        L = mk(0.0, 0.0, 0.0);
+        for (int k = W.nrec[p] - 1; k >= 0; --k) {
+            DMat m = S.mat[W.bod[(size_t)k * W.cap + p]];
+            L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
+        }
+    } else {
+        L = load3(W.L, W.cap, p, 0);
+    }
+    const size_t b = p / J, j = p % J;
+    double* out = samples + b * 3 * J + j;
+    out[0] = L.x;
+    out[J] = L.y;
+    out[2 * J] = L.z;
+}
+
+}  // namespace ptw

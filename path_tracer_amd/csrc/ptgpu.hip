@@ -22,6 +22,7 @@
 
 #include "../../include/ptgpu.h"
 #include "pt_device.hpp"
+#include "pt_wavefront.hpp"
 
 using namespace ptd;
 
@@ -133,13 +134,17 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 }
 
 // ---- k_trace -----------------------------------------------------------------------------
+// __launch_bounds__(256, 5): five 256-thread blocks per CU (5 waves per SIMD).  Their LDS records
+// (5 x 32000 B) just fit the 160 KiB of a CU and the register file allows 96 VGPRs per lane; the
+// estimator is latency-bound on FP64 dependency chains, and the fifth wave buys ~8 %.  The variant
+// with the measured-BRDF lookup (sin/cos/acos/atan2 expansions) needs ~240 registers and runs at 2.
 template <int EST, bool MEASURED>
-__global__ void __launch_bounds__(kBlock) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
     __shared__ double s_pts[kMaxDepth * 3 * kBlock];
-    __shared__ int32_t s_bod[kMaxDepth * kBlock];
+    __shared__ int8_t s_bod[kMaxDepth * kBlock];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int W = S.width, H = S.height;
@@ -172,6 +177,16 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene S, Partition P, int fir
     out[0] = rgb.x;
     out[sample_stride] = rgb.y;
     out[2 * sample_stride] = rgb.z;
+}
+
+// ---- wavefront pipeline: generate stage (the other stages are in pt_wavefront.hpp) -----------
+__global__ void __launch_bounds__(kBlock) k_wf_generate(DScene S, Partition P, int first_it,
+                                                        const double* __restrict__ xs, const double* __restrict__ ys,
+                                                        const int32_t* __restrict__ row_start,
+                                                        const int32_t* __restrict__ npix, double xstep, ptw::WfState W,
+                                                        size_t J) {
+    ptw::wf_generate_body(S, P, [](const Partition& Pp, int q, int tid, int Wd, int H) { return slot_of(Pp, q, tid, Wd, H); },
+                          first_it, xs, ys, row_start, npix, xstep, kXStride, W, J);
 }
 
 // ---- k_accumulate ------------------------------------------------------------------------
@@ -225,7 +240,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_paths(DScene S, const int32_t*
                                                         int32_t* nrec, int32_t* bodies, double* points,
                                                         int32_t* visible, int32_t* used) {
     __shared__ double s_pts[kMaxDepth * 3 * kBlock];
-    __shared__ int32_t s_bod[kMaxDepth * kBlock];
+    __shared__ int8_t s_bod[kMaxDepth * kBlock];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Draws dr;
@@ -338,6 +353,10 @@ struct pt_scene {
     size_t ev_used = 0;
     double last_paths = 0;
     bool has_measured = false;  // any PT_MEASURED body: selects the kernel variant with the table lookup
+    int pipeline = PT_PIPELINE_AUTO;
+    int wf_batch = 1;  // iterations per wavefront batch
+    DevBuf d_wf;       // one allocation carved into the wavefront state arrays
+    ptw::WfState wf;
 };
 
 namespace {
@@ -358,6 +377,9 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
     size_t b = ((size_t)1 << 24) / per_it;
     s->batch = (int)std::min<size_t>(64, std::max<size_t>(1, b));
+    // the wavefront pipeline keeps ~300 B of state per path in HBM: about 2^21 paths per batch
+    size_t wb = ((size_t)1 << 21) / per_it;
+    s->wf_batch = (int)std::min<size_t>((size_t)s->batch, std::max<size_t>(1, wb));
     return PT_OK;
 }
 
@@ -439,6 +461,66 @@ int upload_scene(pt_scene* s) {
         D.cam_xd[k] = s->camera.topright[k] - s->camera.topleft[k];
         D.cam_yd[k] = s->camera.bottomleft[k] - s->camera.topleft[k];
     }
+    return PT_OK;
+}
+
+constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
+
+int ensure_wavefront_buffers(pt_scene* s) {
+    const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
+    const size_t cap = J * (size_t)s->wf_batch;
+    if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
+    // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, queue 6 = 18
+    size_t bytes = cap * (27 * sizeof(double) + 18 * sizeof(int32_t)) + 64;
+    int rc = s->d_wf.ensure(bytes);
+    if (rc) return rc;
+    ptw::WfState& W = s->wf;
+    double* d = (double*)s->d_wf.p;
+    W.ray = d;
+    W.xy = W.ray + 6 * cap;
+    W.pts = W.xy + 2 * cap;
+    W.L = W.pts + 15 * cap;
+    W.t = W.L + 3 * cap;
+    uint32_t* u = (uint32_t*)(W.t + cap);
+    W.rng = u;
+    int32_t* w = (int32_t*)(u + 4 * cap);
+    W.hit = w;
+    W.bod = W.hit + cap;
+    W.nrec = W.bod + 5 * cap;
+    W.light = W.nrec + cap;
+    W.queue = W.light + cap;
+    W.qcount = W.queue + 6 * cap;
+    W.cap = cap;
+    return PT_OK;
+}
+
+// One batch through the wavefront pipeline (see pt_wavefront.hpp).
+int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* xs, const double* ys, const int32_t* rs,
+                     const int32_t* npix, double* samples, size_t J) {
+    using namespace ptw;
+    const WfState W = s->wf;
+    const Partition P = s->part;
+    const int nblk = (int)((J * (size_t)B + kWfBlock - 1) / kWfBlock);
+    HIP_TRY(hipMemsetAsync(W.qcount, 0, 8 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
+    for (int depth = 0; depth < kMaxDepth; ++depth) {
+        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, 0);
+        hipLaunchKernelGGL(k_wf_shade, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, depth);
+    }
+    if (s->estimator == PT_EST_NEE) {
+        hipLaunchKernelGGL(k_wf_light, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W);
+        for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
+            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi + 1, gi);
+            if (s->has_measured)
+                hipLaunchKernelGGL((k_wf_nee<true, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
+            else
+                hipLaunchKernelGGL((k_wf_nee<false, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
+        }
+        hipLaunchKernelGGL((k_wf_finish<kEstNEE>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
+    } else {
+        hipLaunchKernelGGL((k_wf_finish<kEstPT>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
+    }
+    HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 
@@ -529,6 +611,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_npix.release();
     s->d_samples.release();
     s->d_accum.release();
+    s->d_wf.release();
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
     return PT_OK;
@@ -579,6 +662,14 @@ int pt_set_partition(pt_scene* s, int rank, int world, int tile_w, int tile_h) {
     return setup_partition(s, rank, world, tile_w, tile_h);
 }
 
+int pt_set_pipeline(pt_scene* s, int pipeline) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (pipeline != PT_PIPELINE_AUTO && pipeline != PT_PIPELINE_FUSED && pipeline != PT_PIPELINE_WAVEFRONT)
+        return fail(PT_ERR_INVALID, "pt_set_pipeline: unknown pipeline");
+    s->pipeline = pipeline;
+    return PT_OK;
+}
+
 int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double* accum_dev, void* stream_) {
     if (!s || !accum_dev) return fail(PT_ERR_INVALID, "pt_render_device: null argument");
     if (n_iterations < 0 || first_iteration < 0) return fail(PT_ERR_INVALID, "pt_render_device: negative iteration range");
@@ -599,8 +690,14 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     int32_t* npix = (int32_t*)s->d_npix.p;
     double* samples = (double*)s->d_samples.p;
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
-    for (int done = 0; done < n_iterations; done += s->batch) {
-        int B = std::min(s->batch, n_iterations - done);
+    const bool use_wavefront = s->pipeline == PT_PIPELINE_WAVEFRONT ||
+                               (s->pipeline == PT_PIPELINE_AUTO && (int)s->bodies.size() > kMaxBodiesFused);
+    if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
+        return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
+    const int batch = use_wavefront ? s->wf_batch : s->batch;
+    if (use_wavefront && (rc = ensure_wavefront_buffers(s))) return rc;
+    for (int done = 0; done < n_iterations; done += batch) {
+        int B = std::min(batch, n_iterations - done);
         int it0 = first_iteration + done;
         hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, st, s->seed, W, H, it0, s->xstep, s->ystep, xs,
                            ys, rs, npix);
@@ -613,7 +710,10 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         }
         HIP_TRY(hipEventRecord(s->ev[s->ev_used], st));
         dim3 grid(P.owned_tiles, B);
-        if (s->estimator == PT_EST_NEE && s->has_measured)
+        if (use_wavefront) {
+            int rcw = render_wavefront(s, st, it0, B, xs, ys, rs, npix, samples, J);
+            if (rcw) return rcw;
+        } else if (s->estimator == PT_EST_NEE && s->has_measured)
             hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
         else if (s->estimator == PT_EST_NEE)
             hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);

@@ -232,3 +232,69 @@ def test_errors_are_reported_not_fatal():
     with pytest.raises(pt.PtError):
         r.set_partition(0, 1, 10, 10)  # tile must hold 256 pixels
     r.close()
+
+
+def open_scene(name, W, H, seed, drop=(7, 8, 9, 10, 11, 12, 13)):
+    """A reference scene with some walls removed, so that paths leave the scene and terminate."""
+    d = pt.preset(name, W, H, seed=seed)
+    keep = [i for i in range(d.body_count) if i not in drop]
+    bodies = (pt.Body * len(keep))()
+    for k, i in enumerate(keep):
+        bodies[k] = d.bodies[i]
+    d.bodies = bodies
+    d.body_count = len(keep)
+    d._keep = bodies
+    return d
+
+
+@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 70, 40, 4), ("main32", 48, 48, 3), ("nee15_lit", 64, 24, 3)])
+def test_wavefront_equals_fused_and_oracle(port, name, W, H, n_it):
+    r = pt.Renderer(pt.preset(name, W, H, seed=31))
+    want, _ = port.render(oracle_scene(port, r, W, H, 31), MODE_PIXEL, 2, n_it)
+    fused = r.render(2, n_it)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    wave = r.render(2, n_it)
+    assert same_bits(fused, want) and same_bits(wave, want)
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["nee15", "main32"])
+def test_open_scene_paths_terminate(port, name):
+    # only the floor plane and the spheres are kept (every other plane is infinite and would close the
+    # scene again): upward rays escape, queues shrink
+    W, H = 64, 48
+    r = pt.Renderer(open_scene(name, W, H, 17))
+    s = oracle_scene(port, r, W, H, 17)
+    want, _ = port.render(s, MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    assert same_bits(r.render(0, 3), want)
+    rng = np.random.default_rng(5)
+    n = 4000
+    it_idx = np.stack([rng.integers(0, 100, n), rng.integers(0, W * H, n)], axis=1).astype(np.int32)
+    xy = rng.uniform(0, 1, size=(n, 2))
+    r.set_pipeline(pt.PIPELINE_FUSED)
+    g = r.trace_paths(it_idx, xy)
+    o = port.trace_paths(s, it_idx, xy)
+    assert np.array_equal(g["nrec"], o["nrec"]) and (g["nrec"] < 5).mean() > 0.3
+    assert np.array_equal(g["bodies"], o["bodies"]) and same_bits(g["rgb"], o["rgb"])
+    r.close()
+
+
+def test_large_scene_uses_lds_tiled_scan(port):
+    # 1000 and 10000 bodies: beyond the fused kernel's limit, the wavefront pipeline is selected
+    for name, W, H, n_it in (("synthetic1k", 24, 16, 2), ("synthetic10k", 10, 6, 1)):
+        r = pt.Renderer(pt.preset(name, W, H, seed=9))
+        s = oracle_scene(port, r, W, H, 9)
+        want, _ = port.render(s, MODE_PIXEL, 0, n_it)
+        assert same_bits(r.render(0, n_it), want), name
+        rng = np.random.default_rng(3)
+        rays = np.concatenate([np.stack([rng.uniform(-1.8, 1.8, 500), rng.uniform(-2.4, 4.4, 500), rng.uniform(-0.45, 2.4, 500)], axis=1),
+                               rng.normal(size=(500, 3))], axis=1)
+        idx, t = r.intersect_batch(rays)
+        _, idx0, t0 = port.intersect(s, rays)
+        assert np.array_equal(idx, idx0) and same_bits(t, t0)
+        with pytest.raises(pt.PtError):
+            r.set_pipeline(pt.PIPELINE_FUSED)
+            r.render(0, 1)
+        r.close()
