@@ -19,9 +19,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# Algorithmic work per path of the 15-body NEE scene: 5 gather scans of 15 bodies + 5 shadow scans of
-# 14 bodies at 14 flop per plane test and 19 per sphere test = 5*245 + 5*226.
-FLOP_PER_PATH_NEE15 = 2355.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flop
 
 
@@ -78,6 +75,7 @@ def main():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--iterations", type=int, default=7200)
     ap.add_argument("--scene", default="nee15")
+    ap.add_argument("--pipeline", default="", choices=["", "fused", "wavefront"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -99,7 +97,21 @@ def main():
     pt.set_device(local_rank)
 
     W, H, IT = args.width, args.height, args.iterations
-    r = pt.Renderer(pt.preset(args.scene, W, H, seed=1))
+    desc = pt.preset(args.scene, W, H, seed=1)
+    r = pt.Renderer(desc)
+    if args.pipeline:
+        r.set_pipeline({"fused": pt.PIPELINE_FUSED, "wavefront": pt.PIPELINE_WAVEFRONT}[args.pipeline])
+    # algorithmic work per path: 14 flop per plane test, 19 per sphere test; 5 gather scans over all
+    # bodies (+ for NEE 5 shadow scans that leave out the chosen light, the last emitter)
+    planes = sum(1 for i in range(desc.body_count) if desc.bodies[i].shape == pt.PLANE)
+    spheres = desc.body_count - planes
+    scan = 14.0 * planes + 19.0 * spheres
+    flop_per_path = 5.0 * scan
+    rays_per_path = 5
+    if desc.estimator == pt.EST_NEE:
+        lights = [i for i in range(desc.body_count) if max(desc.bodies[i].emission) >= 1.0]
+        flop_per_path += 5.0 * (scan - (19.0 if desc.bodies[lights[-1]].shape == pt.SPHERE else 14.0))
+        rays_per_path = 10
     r.set_partition(rank, world, 32, 8)
     accum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -152,9 +164,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"next_event.cpp 15-body scene, {W}x{H}, {IT} iterations (spp), seed 1",
-                "rays_per_path": 10,
-                "rays_per_s": 10 * paths / elapsed,
+                "workload": f"{args.scene} scene ({desc.body_count} bodies), {W}x{H}, {IT} iterations (spp), seed 1",
+                "rays_per_path": rays_per_path,
+                "rays_per_s": rays_per_path * paths / elapsed,
+                "bodies": desc.body_count,
                 "partition": f"interleaved 32x8 tiles over {world} GPU(s) + RCCL all-reduce of FP64 accumulators",
                 "mean_radiance": checksum,
             },
@@ -162,7 +175,7 @@ def main():
         if world == 1 and launches > 0:
             paths_per_launch = float(W) * H * IT * args.steps / launches
             avg_ms = kernel_ms / launches
-            achieved = paths_per_launch * FLOP_PER_PATH_NEE15 / (avg_ms * 1e-3) / 1e12
+            achieved = paths_per_launch * flop_per_path / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "valu_fp64",
                 "achieved": achieved,
@@ -174,7 +187,7 @@ def main():
                 "kernel": "k_trace<NEE>",
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
-                "flop_per_path": FLOP_PER_PATH_NEE15,
+                "flop_per_path": flop_per_path,
             }
             if not args.no_cpu:
                 cb = cpu_baseline(W, H, args.cpu_seconds)
