@@ -84,6 +84,7 @@ def main():
     import torch.distributed as dist
 
     import path_tracer_amd as pt
+    from path_tracer_amd import distributed as ptdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,15 +113,12 @@ def main():
         lights = [i for i in range(desc.body_count) if max(desc.bodies[i].emission) >= 1.0]
         flop_per_path += 5.0 * (scan - (19.0 if desc.bodies[lights[-1]].shape == pt.SPHERE else 14.0))
         rays_per_path = 10
-    r.set_partition(rank, world, 32, 8)
     accum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         accum.zero_()
-        r.render_device(0, IT, accum.data_ptr(), stream)
-        if world > 1:
-            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+        ptdist.render_distributed(r, 0, IT, accum, rank, world, stream)
 
     def fence():
         torch.cuda.synchronize()

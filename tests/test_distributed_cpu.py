@@ -1,0 +1,59 @@
+"""The N > 1 path on CPU: two gloo ranks, each contributing only its interleaved tiles, must
+reproduce the whole frame bit for bit after the all-reduce.  The per-rank renderer is stood in for
+by the CPU oracle (test infrastructure); tile ownership and the reduction are the product's code."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from path_tracer_amd import distributed as ptd
+
+
+@pytest.mark.parametrize("W,H,world", [(100, 37, 2), (64, 64, 3), (1024, 768, 8), (33, 7, 4), (5, 5, 8)])
+def test_tiles_partition_the_image(W, H, world):
+    owner = ptd.tile_owner(W, H, world)
+    assert owner.shape == (H, W) and owner.min() >= 0 and owner.max() < world
+    total = sum(ptd.owned_mask(W, H, r, world).astype(int) for r in range(world))
+    assert (total == 1).all()
+    # interleaving: consecutive tiles of a tile row belong to consecutive ranks
+    if W > ptd.TILE_W:
+        assert owner[0, ptd.TILE_W] == (owner[0, 0] + 1) % world
+    # balance: no rank owns more than one tile above the mean
+    tiles = -(-W // ptd.TILE_W) * -(-H // ptd.TILE_H)
+    counts = [len(set(zip(*np.nonzero(ptd.owned_mask(W, H, r, world)[:: ptd.TILE_H, :: ptd.TILE_W])))) for r in range(world)]
+    assert max(counts) - min(counts) <= 1 and sum(counts) == tiles
+
+
+def _worker(rank, world, port, W, H, frame_path, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = np.load(frame_path)
+    part = np.where(ptd.owned_mask(W, H, rank, world)[:, :, None], frame, 0.0)
+    accum = torch.from_numpy(part.reshape(-1).copy())
+    ptd.all_reduce_accumulator(accum)
+    if rank == 0:
+        np.save(out_path, accum.numpy().reshape(H, W, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_whole_frame(port, golden_scene, tmp_path):
+    import _oracle
+
+    W, H = 70, 20
+    s = port.scene(*golden_scene("nee15"), W, H, _oracle.EST_NEE, seed=3)
+    frame, _ = port.render(s, _oracle.MODE_PIXEL, 0, 2)
+    frame_path, out_path = str(tmp_path / "frame.npy"), str(tmp_path / "out.npy")
+    np.save(frame_path, frame)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    free_port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_worker, args=(2, free_port, W, H, frame_path, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    assert np.array_equal(got.view(np.uint64), frame.view(np.uint64))

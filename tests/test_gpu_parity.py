@@ -158,6 +158,9 @@ def test_partition_tiles_sum_to_whole():
             r = pt.Renderer(pt.preset("nee15", W, H, seed=4))
             r.set_partition(rank, world, 32, 8)
             part = r.render(0, 3)
+            from path_tracer_amd import distributed as ptdist
+
+            assert not (part != 0).any(axis=2)[~ptdist.owned_mask(W, H, rank, world)].any()  # host and device agree on ownership
             owned += (part != 0).any(axis=2)
             acc += part
             r.close()
