@@ -22,6 +22,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flop
 
 
+def traffic_bytes_per_launch(paths_per_launch):
+    """HBM bytes per launch of the estimator kernel from the committed PMC passes (FETCH_SIZE x 2 +
+    WRITE_SIZE, per path), scaled to this run's launch size; None when no such measurement exists."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["bytes_per_path"] * paths_per_launch
+
+
 def cpu_baseline(width, height, seconds_target):
     """The CPU partner timed on this host's cores: the reference's own Renderer::iterate()
     (oracle/_ref) when that build is present, else the C restatement.  Bounded sample."""
@@ -36,16 +46,16 @@ def cpu_baseline(width, height, seconds_target):
         secs, _ = ref.time_iterate(1, width, height, iters, cores, seed=1)
         kind = "reference"
     else:
+        import ctypes
+
         import path_tracer_amd as pt
 
         port = _oracle.Port()
         d = pt.preset("nee15", width, height)
         stored = (_oracle.Body * d.body_count)()
         for i in range(d.body_count):
-            b = pt.Body()
-            b.__dict__.update()
-            tmp = d.bodies[i]
-            pt.lib().pt_body_construct(tmp)
+            tmp = pt.Body.from_buffer_copy(d.bodies[i])
+            pt.lib().pt_body_construct(ctypes.byref(tmp))
             for f, _ in _oracle.Body._fields_:
                 setattr(stored[i], f, getattr(tmp, "reserved" if f == "pad" else f))
         cam = _oracle.Camera()
@@ -181,7 +191,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                 "frac_of_no_fma_ceiling": achieved / (FP64_VALU_PEAK_TFLOPS / 2),
-                "traffic": None,
+                "traffic": traffic_bytes_per_launch(paths_per_launch),
                 "kernel": "k_trace<NEE>",
                 "avg_launch_ms": avg_ms,
                 "launches": launches,

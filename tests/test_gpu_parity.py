@@ -301,3 +301,27 @@ def test_large_scene_uses_lds_tiled_scan(port):
             r.set_pipeline(pt.PIPELINE_FUSED)
             r.render(0, 1)
         r.close()
+
+
+def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
+    """`next_event W H iters threads` and `main ...`: PPM bytes equal save() of the oracle's buffer, with
+    the reference's worker arithmetic (iters/threads frames per worker, divide by the requested total)."""
+    import subprocess
+
+    from conftest import ROOT
+
+    for prog, preset, (W, H, iters, threads) in (("next_event", "nee15", (40, 24, 7, 2)), ("main", "main32", (32, 32, 4, 1))):
+        out = str(tmp_path / f"{prog}.ppm")
+        exe = os.path.join(ROOT, "path_tracer_amd", "bin", prog)
+        subprocess.run([exe, str(W), str(H), str(iters), str(threads), "--seed", "77", "--out", out, "--quiet"],
+                       check=True, timeout=120)
+        r = pt.Renderer(pt.preset(preset, W, H, seed=77))
+        s = oracle_scene(port, r, W, H, 77)
+        per = iters // threads
+        total = np.zeros((H, W, 3))
+        for k in range(threads):
+            priv, _ = port.render(s, MODE_PIXEL, k * per, per)
+            total = priv if threads == 1 else total + priv
+        with open(out, "rb") as f:
+            assert f.read() == port.save_ppm(total, iters, W, H)
+        r.close()
