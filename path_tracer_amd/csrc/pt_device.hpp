@@ -111,9 +111,24 @@ PTD_INLINE double unif_pm1(Draws& d) { return unif(d) * 2.0 - 1.0; }
 // ---- scene records ---------------------------------------------------------------------
 struct DGeom {  // 64 bytes, what the nearest-hit scan reads
     double cx, cy, cz;
-    double nx, ny, nz;  // plane: stored (normalised) normal; sphere: nx = radius*radius
+    double nx;  // plane: stored (normalised) normal x; sphere: radius*radius
+    union {
+        struct {
+            double ny, nz;  // plane normal y, z
+        };
+        struct {
+            float fcx, fcy, fcz, fr2;  // sphere: centre and radius^2 rounded to float (screening only)
+        };
+    };
     int32_t shape;
     int32_t pad[3];
+};
+
+// Per-ray data of the single-precision sphere screen (see scan_sphere).
+struct RayF {
+    float ox, oy, oz, dx, dy, dz;
+    float e_disc;  // |float disc - exact disc| is below this for every sphere of the scene
+    float e_b;     // likewise for b
 };
 struct DMat {  // 96 bytes
     double colr, colg, colb;
@@ -125,11 +140,23 @@ struct DMat {  // 96 bytes
     int32_t pad[4];
 };
 
+// Screening records of the LDS-tiled scan: sphere centre and radius^2 in float, two consecutive
+// bodies interleaved per 32-byte record so that a pair is screened with packed FP32 instructions
+// (v_pk_add/mul/fma_f32).  For every non-sphere (and the padding slot of an odd body count) r2 is
+// NaN, which makes the screen inconclusive so that the full record is examined.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct DScreen2 {
+    f32x2 cx, cy, cz, r2;  // .x: body 2k, .y: body 2k+1
+};
+
 struct DScene {
     const DGeom* geom;
+    const DScreen2* screen;  // ceil(n/2) records
     const DMat* mat;
     const int32_t* lights;  // body indices with any emission channel >= 1 (next_event.cpp:362-367)
     const double* brdf[8];
+    float sphere_c1max;  // max over spheres of |cx|+|cy|+|cz|   (error bound of the float screen)
+    float sphere_r2max;  // max over spheres of radius^2
     int32_t n_bodies;
     int32_t n_lights;
     int32_t width, height;
@@ -192,7 +219,61 @@ PTD_INLINE bool scan_plane_axis(double ck, double ok, double dk, double& t) {
     t = (ck - ok) / dk;
     return !((dk > -0.00001) && (dk < 0.00001));
 }
-PTD_INLINE bool scan_sphere(const DGeom& g, V3 o, V3 d, double& t) {
+// Single-precision screen for Sphere::intersect.  A sphere can only be hit when disc > 0 and b < 0;
+// both are first evaluated in float (13 operations, half of them packed) together with a rigorous
+// bound on the float error, and the double-precision evaluation is skipped for the whole wave when
+// no lane can possibly satisfy them.  Lanes are never decided by float arithmetic: whenever any
+// lane is uncertain the wave takes the exact FP64 path, so results are unchanged.
+//
+// Error bound (eps = 2^-24): with M = 2*(|o|_1 + max|c|_1) >= |D|_1 + |o|_1 + |c|_1 and n = |d|_1,
+//   |b_f - b| <= 12 eps M n,   |disc_f - disc| <= 32 eps (M^2 (n^2 + 1) + r^2);
+// e_b and e_disc carry a further factor 2..4 of safety.  NaN/inf compare false and fall through.
+PTD_INLINE RayF make_rayf(V3 o, V3 d, float c1max, float r2max) {
+    RayF r;
+    r.ox = (float)o.x;
+    r.oy = (float)o.y;
+    r.oz = (float)o.z;
+    r.dx = (float)d.x;
+    r.dy = (float)d.y;
+    r.dz = (float)d.z;
+    float M = 2.0f * ((__builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz)) + c1max) * 1.0001f;
+    float n = (__builtin_fabsf(r.dx) + __builtin_fabsf(r.dy) + __builtin_fabsf(r.dz)) * 1.0001f;
+    r.e_disc = 0x1p-18f * (M * M * (n * n + 1.0f) + r2max);
+    r.e_b = 0x1p-19f * M * n;
+    return r;
+}
+
+// True when this lane certainly cannot hit the sphere (cx, cy, cz, r2 in float).
+PTD_INLINE bool sphere_impossible(const RayF& rf, float cx, float cy, float cz, float r2) {
+    float Dx = rf.ox - cx, Dy = rf.oy - cy, Dz = rf.oz - cz;
+    float bf = Dx * rf.dx + Dy * rf.dy + Dz * rf.dz;
+    float cf = (Dx * Dx + Dy * Dy + Dz * Dz) - r2;
+    float discf = bf * bf - cf;
+    return (discf < -rf.e_disc) || (bf > rf.e_b);
+}
+
+// The same screen for two bodies at once (packed FP32).  Returns, per lane, bit 0 / bit 1 set when
+// body 0 / 1 MIGHT be hit (NaN compares as "might").
+PTD_INLINE unsigned sphere_possible2(const RayF& rf, const DScreen2& sc) {
+    f32x2 Dx = rf.ox - sc.cx, Dy = rf.oy - sc.cy, Dz = rf.oz - sc.cz;
+    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(rf.dz), __builtin_elementwise_fma(Dy, (f32x2)(rf.dy), Dx * rf.dx));
+    f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
+    f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
+    unsigned p0 = (!(discf.x < -rf.e_disc) && !(bf.x > rf.e_b)) ? 1u : 0u;
+    unsigned p1 = (!(discf.y < -rf.e_disc) && !(bf.y > rf.e_b)) ? 2u : 0u;
+    return p0 | p1;
+}
+
+PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t);
+
+PTD_INLINE bool scan_sphere(const DGeom& g, V3 o, V3 d, const RayF& rf, double& t) {
+    t = 0.0;
+    if (__builtin_amdgcn_ballot_w64(!sphere_impossible(rf, g.fcx, g.fcy, g.fcz, g.fr2)) == 0) return false;
+    return scan_sphere_exact(g, o, d, t);
+}
+
+PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t) {
+    t = 0.0;
     double dx = o.x - g.cx, dy = o.y - g.cy, dz = o.z - g.cz;
     double b = dx * d.x + dy * d.y + dz * d.z;
     double c = (dx * dx + dy * dy + dz * dz) - g.nx;
@@ -200,7 +281,6 @@ PTD_INLINE bool scan_sphere(const DGeom& g, V3 o, V3 d, double& t) {
     // -b - sqrt(disc) can only be positive when b < 0; most (wave, sphere) pairs have no such lane
     // and skip the square root altogether.
     bool ok = (disc > 0.0) && (b < 0.0);
-    t = 0.0;
     if (__builtin_amdgcn_ballot_w64(ok) != 0) {
         double dd = disc;
         asm volatile("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
@@ -212,7 +292,9 @@ PTD_INLINE bool scan_sphere(const DGeom& g, V3 o, V3 d, double& t) {
 // Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint), ties to the larger index;
 // `skip` is the light excluded by next_event.cpp:415-419 (-1: none).  Body records are read at
 // wave-uniform addresses (scalar loads); the shape switch is a scalar branch.
-PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, double& tmin) {
+PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, float c1max, float r2max,
+                           double& tmin) {
+    const RayF rf = make_rayf(o, d, c1max, r2max);
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     for (int i = 0; i < n; ++i) {
@@ -220,7 +302,7 @@ PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, in
         double t;
         bool ok;
         switch (g.shape) {
-            case kSphere: ok = scan_sphere(g, o, d, t); break;
+            case kSphere: ok = scan_sphere(g, o, d, rf, t); break;
             case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
             case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
             case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
@@ -529,7 +611,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 #pragma unroll 1
     for (; n < kMaxDepth; ++n) {
         double mint;
-        int hit = nearest_hit(geom, S.n_bodies, o, d, -1, mint);
+        int hit = nearest_hit(geom, S.n_bodies, o, d, -1, S.sphere_c1max, S.sphere_r2max, mint);
         if (hit < 0) break;
         V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
         rec.put(n, point, hit);
@@ -555,7 +637,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         int target = rec.body(gi);
         V3 bd = normalize(sub(P, T.lc));
         double mint;
-        int hit = nearest_hit(geom, S.n_bodies, T.lc, bd, light, mint);
+        int hit = nearest_hit(geom, S.n_bodies, T.lc, bd, light, S.sphere_c1max, S.sphere_r2max, mint);
         if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
         V3 next_point = campt;

@@ -22,7 +22,7 @@ namespace ptw {
 using namespace ptd;
 
 constexpr int kWfBlock = 256;
-constexpr int kTileBodies = 512;  // 512 x 64 B = 32 KiB of LDS per block
+constexpr int kTileBodies = 512;  // 512 x (64 + 16) B = 40 KiB of LDS per block: 4 blocks per CU
 
 struct WfState {
     double* ray;     // [6][cap]  origin xyz, direction xyz
@@ -75,11 +75,23 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
     a[(size_t)(first + 2) * cap + p] = v.z;
 }
 
-// Nearest-hit scan with the body list staged through LDS in tiles of kTileBodies records.
+// Nearest-hit scan with the body list staged through LDS in tiles of kTileBodies bodies.  A tile
+// holds two images: 32-byte screening records (float sphere data of two consecutive bodies) and the
+// full 64-byte records.  Per pair of bodies a wave reads the screening record (broadcast LDS read)
+// and runs the packed float screen; only when some lane might hit does it read a full record and
+// evaluate in FP64.  In a
+// scene of many small spheres almost every (wave, body) pair ends at the screen, which keeps the
+// LDS pipe (one 64-byte record per body per wave would saturate it) and the FP64 units free.
 // Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
 // Same acceptance rule and body order as ptd::nearest_hit.
-PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, bool active,
-                                 DGeom* s_tile, double& tmin) {
+struct TileLds {
+    DScreen2 scr[kTileBodies / 2];
+    DGeom geom[kTileBodies];
+};
+
+PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2* __restrict__ screen, int n, V3 o, V3 d,
+                                 int skip, bool active, float c1max, float r2max, TileLds* tile, double& tmin) {
+    const RayF rf = make_rayf(o, d, c1max, r2max);
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     for (int base = 0; base < n; base += kTileBodies) {
@@ -87,27 +99,50 @@ PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, int n, V3 o, V3
         __syncthreads();  // the previous tile has been consumed by every wave
         {
             const uint4* src = reinterpret_cast<const uint4*>(geom + base);
-            uint4* dst = reinterpret_cast<uint4*>(s_tile);
+            uint4* dst = reinterpret_cast<uint4*>(tile->geom);
             for (int k = threadIdx.x; k < cnt * 4; k += blockDim.x) dst[k] = src[k];  // 16 B per lane, coalesced
+            const uint4* ssrc = reinterpret_cast<const uint4*>(screen + base / 2);
+            uint4* sdst = reinterpret_cast<uint4*>(tile->scr);
+            const int have = ((cnt + 1) / 2) * 2;    // uint4 units present in global memory
+            const int want = ((cnt + 3) / 4) * 4;    // uint4 units the screening loop reads
+            for (int k = threadIdx.x; k < want; k += blockDim.x)
+                sdst[k] = k < have ? ssrc[k] : make_uint4(0u, 0u, 0u, 0u);  // r2 = 0 at the origin: harmless, index >= cnt is never examined
         }
         __syncthreads();
         if (active) {
-            for (int i = 0; i < cnt; ++i) {
-                DGeom g = s_tile[i];  // same address in every lane: LDS broadcast
-                const int shape = __builtin_amdgcn_readfirstlane(g.shape);
-                double t;
-                bool ok;
-                switch (shape) {
-                    case kSphere: ok = scan_sphere(g, o, d, t); break;
-                    case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
-                    case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
-                    case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
-                    default: ok = scan_plane(g, o, d, t); break;
+            // four bodies (two screening records) per step; the records past the tile's end were
+            // filled with inconclusive-free padding by the loader below
+            const int steps = (cnt + 3) / 4;
+            for (int q = 0; q < steps; ++q) {
+                const DScreen2 sa = tile->scr[2 * q];  // same address in every lane: LDS broadcast
+                const DScreen2 sb = tile->scr[2 * q + 1];
+                const unsigned possible = sphere_possible2(rf, sa) | (sphere_possible2(rf, sb) << 2);
+                // OR over the wave: which of the four bodies needs the exact test by some lane
+                unsigned long long any = __builtin_amdgcn_ballot_w64(possible != 0);
+                if (any == 0) continue;
+                unsigned need = 0;
+                for (int h = 0; h < 4; ++h)
+                    if (__builtin_amdgcn_ballot_w64((possible >> h) & 1u) != 0) need |= 1u << h;
+                for (int h = 0; h < 4; ++h) {
+                    if (!((need >> h) & 1u)) continue;
+                    const int i = 4 * q + h;
+                    if (i >= cnt) break;
+                    DGeom g = tile->geom[i];
+                    const int shape = __builtin_amdgcn_readfirstlane(g.shape);
+                    double t;
+                    bool ok;
+                    switch (shape) {
+                        case kSphere: ok = scan_sphere_exact(g, o, d, t); break;
+                        case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
+                        case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
+                        case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
+                        default: ok = scan_plane(g, o, d, t); break;
+                    }
+                    const int idx = base + i;
+                    bool take = ok && (t > 0.0) && (t <= mint) && (idx != skip);
+                    mint = take ? t : mint;
+                    hit = take ? idx : hit;
                 }
-                const int idx = base + i;
-                bool take = ok && (t > 0.0) && (t <= mint) && (idx != skip);
-                mint = take ? t : mint;
-                hit = take ? idx : hit;
             }
         }
     }
@@ -156,7 +191,7 @@ enum { kGather = 0, kShadow = 1 };
 // One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.
 template <int MODE>
 __global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int qi, int gi) {
-    __shared__ DGeom s_tile[kTileBodies];
+    __shared__ TileLds s_tile;
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
     if ((int)(blockIdx.x * kWfBlock) >= count) return;  // whole block idle
@@ -179,7 +214,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int
         }
     }
     double mint;
-    int hit = nearest_hit_tiled(S.geom, S.n_bodies, o, d, skip, active, s_tile, mint);
+    int hit = nearest_hit_tiled(S.geom, S.screen, S.n_bodies, o, d, skip, active, S.sphere_c1max, S.sphere_r2max, &s_tile, mint);
     if (active) {
         W.hit[p] = hit;
         W.t[p] = mint;

@@ -222,7 +222,7 @@ __global__ void k_intersect_batch(DScene S, const double* __restrict__ rays6, in
     if (i >= n) return;
     V3 o = ld3(rays6 + 6 * (size_t)i), d = ld3(rays6 + 6 * (size_t)i + 3);
     double mint;
-    int hit = nearest_hit(S.geom, S.n_bodies, o, d, skip, mint);
+    int hit = nearest_hit(S.geom, S.n_bodies, o, d, skip, S.sphere_c1max, S.sphere_r2max, mint);
     idx[i] = hit;
     t[i] = mint;
 }
@@ -345,7 +345,7 @@ struct pt_scene {
     std::vector<int32_t> lights;
     Partition part;
     DScene ds;
-    DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
+    DevBuf d_geom, d_mat, d_screen, d_lights, d_brdf[PT_MAX_BRDF];
     DevBuf d_xs, d_ys, d_rowstart, d_npix, d_samples, d_accum;
     double xstep = 0, ystep = 0;
     int batch = 1;
@@ -399,6 +399,12 @@ int upload_scene(pt_scene* s) {
     const int n = (int)s->bodies.size();
     std::vector<DGeom> geom(n);
     std::vector<DMat> mat(n);
+    std::vector<DScreen2> scr((n + 1) / 2);
+    for (auto& r : scr) {
+        r.cx = r.cy = r.cz = f32x2{0.0f, 0.0f};
+        r.r2 = f32x2{std::nanf(""), std::nanf("")};
+    }
+    float c1max = 0.0f, r2max = 0.0f;
     for (int i = 0; i < n; ++i) {
         const pt_body& b = s->bodies[i];
         DGeom g;
@@ -418,8 +424,21 @@ int upload_scene(pt_scene* s) {
             if (g.nx == 0.0 && g.ny == 0.0 && unit(g.nz)) g.shape = kPlaneZ;
         } else {
             g.nx = b.radius * b.radius;  // Sphere ctor radius2 main.cpp:207
+            g.fcx = (float)g.cx;
+            g.fcy = (float)g.cy;
+            g.fcz = (float)g.cz;
+            g.fr2 = (float)g.nx;
+            c1max = std::max(c1max, std::fabs(g.fcx) + std::fabs(g.fcy) + std::fabs(g.fcz));
+            r2max = std::max(r2max, g.fr2);
         }
         geom[i] = g;
+        if (b.shape == PT_SPHERE) {
+            DScreen2& r = scr[i / 2];
+            r.cx[i & 1] = g.fcx;
+            r.cy[i & 1] = g.fcy;
+            r.cz[i & 1] = g.fcz;
+            r.r2[i & 1] = g.fr2;
+        }
         DMat m;
         memset(&m, 0, sizeof m);
         m.colr = b.color[0];
@@ -438,17 +457,22 @@ int upload_scene(pt_scene* s) {
     int rc;
     if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
     if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
+    if ((rc = s->d_screen.ensure(sizeof(DScreen2) * scr.size()))) return rc;
     if ((rc = s->d_lights.ensure(sizeof(int32_t) * std::max<size_t>(1, s->lights.size())))) return rc;
     HIP_TRY(hipMemcpy(s->d_geom.p, geom.data(), sizeof(DGeom) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_mat.p, mat.data(), sizeof(DMat) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_screen.p, scr.data(), sizeof(DScreen2) * scr.size(), hipMemcpyHostToDevice));
     if (!s->lights.empty())
         HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), sizeof(int32_t) * s->lights.size(), hipMemcpyHostToDevice));
     DScene& D = s->ds;
     memset(&D, 0, sizeof D);
     D.geom = (const DGeom*)s->d_geom.p;
     D.mat = (const DMat*)s->d_mat.p;
+    D.screen = (const DScreen2*)s->d_screen.p;
     D.lights = (const int32_t*)s->d_lights.p;
     D.n_bodies = n;
+    D.sphere_c1max = c1max * 1.0001f;
+    D.sphere_r2max = r2max * 1.0001f;
     D.n_lights = (int)s->lights.size();
     D.width = s->width;
     D.height = s->height;
@@ -603,6 +627,7 @@ int pt_scene_destroy(pt_scene* s) {
     (void)hipSetDevice(s->device);
     s->d_geom.release();
     s->d_mat.release();
+    s->d_screen.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
     s->d_xs.release();
