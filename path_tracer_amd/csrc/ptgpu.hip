@@ -346,7 +346,12 @@ struct pt_scene {
     Partition part;
     DScene ds;
     DevBuf d_geom, d_mat, d_screen, d_lights, d_brdf[PT_MAX_BRDF];
-    DevBuf d_xs, d_ys, d_rowstart, d_npix, d_samples, d_accum;
+    // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
+    // batch k-1 overlap the estimator kernel of batch k on two side streams
+    DevBuf d_xs[2], d_ys[2], d_rowstart[2], d_npix[2], d_samples[2], d_accum;
+    hipStream_t st_layout = nullptr, st_accum = nullptr;
+    hipEvent_t ev_entry = nullptr, ev_layout[2] = {nullptr, nullptr}, ev_trace[2] = {nullptr, nullptr},
+               ev_acc[2] = {nullptr, nullptr};
     double xstep = 0, ystep = 0;
     int batch = 1;
     std::vector<hipEvent_t> ev;  // start/stop pairs of the estimator launches of the last render
@@ -386,12 +391,24 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
 int ensure_render_buffers(pt_scene* s) {
     const size_t W = s->width, H = s->height, B = s->batch;
     int rc;
-    if ((rc = s->d_xs.ensure(B * H * ((W + kXStride - 1) / kXStride) * sizeof(double)))) return rc;
-    if ((rc = s->d_ys.ensure(B * H * sizeof(double)))) return rc;
-    if ((rc = s->d_rowstart.ensure(B * (H + 1) * sizeof(int32_t)))) return rc;
-    if ((rc = s->d_npix.ensure(B * sizeof(int32_t)))) return rc;
     size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
-    if ((rc = s->d_samples.ensure(B * 3 * J * sizeof(double)))) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = s->d_xs[k].ensure(B * H * ((W + kXStride - 1) / kXStride) * sizeof(double)))) return rc;
+        if ((rc = s->d_ys[k].ensure(B * H * sizeof(double)))) return rc;
+        if ((rc = s->d_rowstart[k].ensure(B * (H + 1) * sizeof(int32_t)))) return rc;
+        if ((rc = s->d_npix[k].ensure(B * sizeof(int32_t)))) return rc;
+        if ((rc = s->d_samples[k].ensure(B * 3 * J * sizeof(double)))) return rc;
+    }
+    if (!s->st_layout) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->st_layout, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s->st_accum, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_entry, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_layout[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_trace[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_acc[k], hipEventDisableTiming));
+        }
+    }
     return PT_OK;
 }
 
@@ -630,11 +647,19 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_screen.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
-    s->d_xs.release();
-    s->d_ys.release();
-    s->d_rowstart.release();
-    s->d_npix.release();
-    s->d_samples.release();
+    for (int k = 0; k < 2; ++k) {
+        s->d_xs[k].release();
+        s->d_ys[k].release();
+        s->d_rowstart[k].release();
+        s->d_npix[k].release();
+        s->d_samples[k].release();
+        if (s->ev_layout[k]) (void)hipEventDestroy(s->ev_layout[k]);
+        if (s->ev_trace[k]) (void)hipEventDestroy(s->ev_trace[k]);
+        if (s->ev_acc[k]) (void)hipEventDestroy(s->ev_acc[k]);
+    }
+    if (s->ev_entry) (void)hipEventDestroy(s->ev_entry);
+    if (s->st_layout) (void)hipStreamDestroy(s->st_layout);
+    if (s->st_accum) (void)hipStreamDestroy(s->st_accum);
     s->d_accum.release();
     s->d_wf.release();
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
@@ -709,11 +734,6 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     if (P.owned_tiles == 0 || n_iterations == 0) return PT_OK;
     const int W = s->width, H = s->height;
     const size_t J = (size_t)P.owned_tiles * kBlock;
-    double* xs = (double*)s->d_xs.p;
-    double* ys = (double*)s->d_ys.p;
-    int32_t* rs = (int32_t*)s->d_rowstart.p;
-    int32_t* npix = (int32_t*)s->d_npix.p;
-    double* samples = (double*)s->d_samples.p;
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const bool use_wavefront = s->pipeline == PT_PIPELINE_WAVEFRONT ||
                                (s->pipeline == PT_PIPELINE_AUTO && (int)s->bodies.size() > kMaxBodiesFused);
@@ -721,11 +741,37 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
     const int batch = use_wavefront ? s->wf_batch : s->batch;
     if (use_wavefront && (rc = ensure_wavefront_buffers(s))) return rc;
-    for (int done = 0; done < n_iterations; done += batch) {
-        int B = std::min(batch, n_iterations - done);
-        int it0 = first_iteration + done;
-        hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, st, s->seed, W, H, it0, s->xstep, s->ystep, xs,
-                           ys, rs, npix);
+    const int nbatch = (n_iterations + batch - 1) / batch;
+    // Three streams: the caller's stream runs the estimator kernels back to back; the frame layout
+    // of the next batch runs ahead on st_layout, the accumulation of the previous batch trails on
+    // st_accum.  Batch k uses buffer set k & 1.  Everything is ordered after the work already
+    // queued on the caller's stream, and the caller's stream ends up waiting for the last accumulation.
+    HIP_TRY(hipEventRecord(s->ev_entry, st));
+    HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_entry, 0));
+    HIP_TRY(hipStreamWaitEvent(s->st_accum, s->ev_entry, 0));
+    auto launch_layout = [&](int k) -> int {
+        const int q = k & 1;
+        const int B = std::min(batch, n_iterations - k * batch);
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_trace[q], 0));  // batch k-2 has read these tables
+        hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, s->st_layout, s->seed, W, H,
+                           first_iteration + k * batch, s->xstep, s->ystep, (double*)s->d_xs[q].p, (double*)s->d_ys[q].p,
+                           (int32_t*)s->d_rowstart[q].p, (int32_t*)s->d_npix[q].p);
+        HIP_TRY(hipEventRecord(s->ev_layout[q], s->st_layout));
+        return PT_OK;
+    };
+    if ((rc = launch_layout(0))) return rc;
+    for (int k = 0; k < nbatch; ++k) {
+        const int q = k & 1;
+        const int B = std::min(batch, n_iterations - k * batch);
+        const int it0 = first_iteration + k * batch;
+        const double* xs = (const double*)s->d_xs[q].p;
+        const double* ys = (const double*)s->d_ys[q].p;
+        const int32_t* rs = (const int32_t*)s->d_rowstart[q].p;
+        const int32_t* npix = (const int32_t*)s->d_npix[q].p;
+        double* samples = (double*)s->d_samples[q].p;
+        if (k + 1 < nbatch && (rc = launch_layout(k + 1))) return rc;
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_layout[q], 0));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(st, s->ev_acc[q], 0));  // batch k-2's samples have been consumed
         if (s->ev.size() < s->ev_used + 2) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -746,9 +792,13 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
             hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
         HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], st));
         s->ev_used += 2;
-        hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, st, P, W, H, B, npix, samples, J, accum_dev);
+        HIP_TRY(hipEventRecord(s->ev_trace[q], st));
+        HIP_TRY(hipStreamWaitEvent(s->st_accum, s->ev_trace[q], 0));
+        hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, s->st_accum, P, W, H, B, npix, samples, J, accum_dev);
+        HIP_TRY(hipEventRecord(s->ev_acc[q], s->st_accum));
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_acc[(nbatch - 1) & 1], 0));
     s->last_paths = (double)n_iterations * (double)J;  // upper bound: includes out-of-image lanes of edge tiles
     return PT_OK;
 }
@@ -876,13 +926,13 @@ int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t*
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const int CK = (W + kXStride - 1) / kXStride;
     hipLaunchKernelGGL(k_frame_layout, dim3(1), dim3(layout_threads), 0, 0, s->seed, W, H, iteration, s->xstep, s->ystep,
-                       (double*)s->d_xs.p, (double*)s->d_ys.p, (int32_t*)s->d_rowstart.p, (int32_t*)s->d_npix.p);
+                       (double*)s->d_xs[0].p, (double*)s->d_ys[0].p, (int32_t*)s->d_rowstart[0].p, (int32_t*)s->d_npix[0].p);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> rs(H + 1);
     std::vector<double> ck((size_t)H * CK);
-    HIP_TRY(hipMemcpy(ck.data(), s->d_xs.p, sizeof(double) * ck.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ys, s->d_ys.p, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(rs.data(), s->d_rowstart.p, sizeof(int32_t) * (H + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ck.data(), s->d_xs[0].p, sizeof(double) * ck.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ys, s->d_ys[0].p, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rs.data(), s->d_rowstart[0].p, sizeof(int32_t) * (H + 1), hipMemcpyDeviceToHost));
     int nr = 0;
     for (int r = 0; r < H; ++r) {
         row_len[r] = rs[r + 1] - rs[r];
