@@ -152,6 +152,12 @@ struct DScreen2 {
 struct DScene {
     const DGeom* geom;
     const DScreen2* screen;  // ceil(n/2) records
+    // Compact lists of the fused scan (body index in pad[0]): planes, then spheres padded to an
+    // even count with a record whose screen can never pass, and the spheres' paired screen records.
+    const DGeom* scan_planes;
+    const DGeom* scan_spheres;
+    const DScreen2* scan_screen;
+    int32_t n_planes, n_spheres;
     const DMat* mat;
     const int32_t* lights;  // body indices with any emission channel >= 1 (next_event.cpp:362-367)
     const double* brdf[8];
@@ -254,14 +260,18 @@ PTD_INLINE bool sphere_impossible(const RayF& rf, float cx, float cy, float cz, 
 
 // The same screen for two bodies at once (packed FP32).  Returns, per lane, bit 0 / bit 1 set when
 // body 0 / 1 MIGHT be hit (NaN compares as "might").
-PTD_INLINE unsigned sphere_possible2(const RayF& rf, const DScreen2& sc) {
-    f32x2 Dx = rf.ox - sc.cx, Dy = rf.oy - sc.cy, Dz = rf.oz - sc.cz;
-    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(rf.dz), __builtin_elementwise_fma(Dy, (f32x2)(rf.dy), Dx * rf.dx));
+PTD_INLINE unsigned sphere_possible2(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc, float e_b,
+                                     const DScreen2& sc) {
+    f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
+    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
     f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
     f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
-    unsigned p0 = (!(discf.x < -rf.e_disc) && !(bf.x > rf.e_b)) ? 1u : 0u;
-    unsigned p1 = (!(discf.y < -rf.e_disc) && !(bf.y > rf.e_b)) ? 2u : 0u;
+    unsigned p0 = (!(discf.x < -e_disc) && !(bf.x > e_b)) ? 1u : 0u;
+    unsigned p1 = (!(discf.y < -e_disc) && !(bf.y > e_b)) ? 2u : 0u;
     return p0 | p1;
+}
+PTD_INLINE unsigned sphere_possible2(const RayF& rf, const DScreen2& sc) {
+    return sphere_possible2(rf.ox, rf.oy, rf.oz, rf.dx, rf.dy, rf.dz, rf.e_disc, rf.e_b, sc);
 }
 
 PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t);
@@ -289,31 +299,59 @@ PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t) {
     return ok;
 }
 
-// Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint), ties to the larger index;
-// `skip` is the light excluded by next_event.cpp:415-419 (-1: none).  Body records are read at
-// wave-uniform addresses (scalar loads); the shape switch is a scalar branch.
-PTD_INLINE int nearest_hit(const DGeom* __restrict__ geom, int n, V3 o, V3 d, int skip, float c1max, float r2max,
-                           double& tmin) {
-    const RayF rf = make_rayf(o, d, c1max, r2max);
+// Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint) over the bodies in index order, i.e.
+// the smallest positive t with ties going to the larger index; `skip` is the light excluded by
+// next_event.cpp:415-419 (-1: none).  That result does not depend on the order of evaluation, so
+// the scan walks two compact lists built at upload (body index in pad[0]):
+//  1. planes in ascending order with the reference's own `t <= mint` rule;
+//  2. spheres, two per step: the packed single-precision screen decides per wave whether either
+//     needs its exact FP64 evaluation; an exact result is merged with the explicit rule
+//     (t < mint) || (t == mint && index > hit).
+// Records are read at wave-uniform addresses (scalar loads); the shape switch is a scalar branch.
+PTD_INLINE void merge_sphere(const DGeom& g, V3 o, V3 d, int skip, int& hit, double& mint) {
+    double t;
+    bool ok = scan_sphere_exact(g, o, d, t);
+    const int i = g.pad[0];
+    bool take = ok && (t > 0.0) && ((t < mint) || ((t == mint) && (i > hit))) && (i != skip);
+    mint = take ? t : mint;
+    hit = take ? i : hit;
+}
+PTD_INLINE int nearest_hit_lists(const DGeom* __restrict__ planes, int n_planes, const DGeom* __restrict__ spheres,
+                                 const DScreen2* __restrict__ screen, int n_spheres, float c1max, float r2max, V3 o,
+                                 V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    for (int i = 0; i < n; ++i) {
-        DGeom g = geom[i];
+    for (int k = 0; k < n_planes; ++k) {
+        DGeom g = planes[k];
         double t;
         bool ok;
         switch (g.shape) {
-            case kSphere: ok = scan_sphere(g, o, d, rf, t); break;
             case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
             case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
             case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
             default: ok = scan_plane(g, o, d, t); break;
         }
+        const int i = g.pad[0];
         bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
         mint = take ? t : mint;
         hit = take ? i : hit;
     }
+    if (n_spheres > 0) {
+        const RayF rf = make_rayf(o, d, c1max, r2max);
+        const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
+        const float e_disc = rf.e_disc, e_b = rf.e_b;
+        for (int k = 0; 2 * k < n_spheres; ++k) {
+            const unsigned m = sphere_possible2(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, screen[k]);
+            if (__builtin_amdgcn_ballot_w64((m & 1u) != 0) != 0) merge_sphere(spheres[2 * k], o, d, skip, hit, mint);
+            if (__builtin_amdgcn_ballot_w64((m & 2u) != 0) != 0) merge_sphere(spheres[2 * k + 1], o, d, skip, hit, mint);
+        }
+    }
     tmin = mint;
     return hit;
+}
+PTD_INLINE int nearest_hit(const DScene& S, V3 o, V3 d, int skip, double& tmin) {
+    return nearest_hit_lists(S.scan_planes, S.n_planes, S.scan_spheres, S.scan_screen, S.n_spheres, S.sphere_c1max,
+                             S.sphere_r2max, o, d, skip, tmin);
 }
 
 // ---- materials -------------------------------------------------------------------------
@@ -611,7 +649,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 #pragma unroll 1
     for (; n < kMaxDepth; ++n) {
         double mint;
-        int hit = nearest_hit(geom, S.n_bodies, o, d, -1, S.sphere_c1max, S.sphere_r2max, mint);
+        int hit = nearest_hit(S, o, d, -1, mint);
         if (hit < 0) break;
         V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
         rec.put(n, point, hit);
@@ -637,7 +675,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         int target = rec.body(gi);
         V3 bd = normalize(sub(P, T.lc));
         double mint;
-        int hit = nearest_hit(geom, S.n_bodies, T.lc, bd, light, S.sphere_c1max, S.sphere_r2max, mint);
+        int hit = nearest_hit(S, T.lc, bd, light, mint);
         if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
         V3 next_point = campt;

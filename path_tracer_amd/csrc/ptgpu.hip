@@ -222,7 +222,7 @@ __global__ void k_intersect_batch(DScene S, const double* __restrict__ rays6, in
     if (i >= n) return;
     V3 o = ld3(rays6 + 6 * (size_t)i), d = ld3(rays6 + 6 * (size_t)i + 3);
     double mint;
-    int hit = nearest_hit(S.geom, S.n_bodies, o, d, skip, S.sphere_c1max, S.sphere_r2max, mint);
+    int hit = nearest_hit(S, o, d, skip, mint);
     idx[i] = hit;
     t[i] = mint;
 }
@@ -346,6 +346,7 @@ struct pt_scene {
     Partition part;
     DScene ds;
     DevBuf d_geom, d_mat, d_screen, d_lights, d_brdf[PT_MAX_BRDF];
+    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
     DevBuf d_xs[2], d_ys[2], d_rowstart[2], d_npix[2], d_samples[2], d_accum;
@@ -471,7 +472,42 @@ int upload_scene(pt_scene* s) {
         m.brdf_id = b.brdf_id;
         mat[i] = m;
     }
+    // Compact lists of the fused scan: planes and spheres in ascending body order, body index in
+    // pad[0]; an odd sphere count is padded with a record whose screen never passes (r2 = -inf).
+    std::vector<DGeom> scan_planes, scan_spheres;
+    for (int i = 0; i < n; ++i) {
+        DGeom g = geom[i];
+        g.pad[0] = i;
+        (g.shape == kSphere ? scan_spheres : scan_planes).push_back(g);
+    }
+    const int n_planes = (int)scan_planes.size(), n_spheres = (int)scan_spheres.size();
+    if (n_spheres & 1) {
+        DGeom g;
+        memset(&g, 0, sizeof g);
+        g.nx = -1.0;  // radius^2 < 0: the exact test cannot pass either
+        g.fr2 = -INFINITY;
+        g.shape = kSphere;
+        g.pad[0] = -1;
+        scan_spheres.push_back(g);
+    }
+    std::vector<DScreen2> scan_screen(scan_spheres.size() / 2);
+    for (size_t k = 0; k < scan_spheres.size(); ++k) {
+        DScreen2& r = scan_screen[k / 2];
+        r.cx[k & 1] = scan_spheres[k].fcx;
+        r.cy[k & 1] = scan_spheres[k].fcy;
+        r.cz[k & 1] = scan_spheres[k].fcz;
+        r.r2[k & 1] = scan_spheres[k].fr2;
+    }
+    if (scan_planes.empty()) scan_planes.resize(1);
+    if (scan_spheres.empty()) scan_spheres.resize(2);
+    if (scan_screen.empty()) scan_screen.resize(1);
     int rc;
+    if ((rc = s->d_scan_planes.ensure(sizeof(DGeom) * scan_planes.size()))) return rc;
+    if ((rc = s->d_scan_spheres.ensure(sizeof(DGeom) * scan_spheres.size()))) return rc;
+    if ((rc = s->d_scan_screen.ensure(sizeof(DScreen2) * scan_screen.size()))) return rc;
+    HIP_TRY(hipMemcpy(s->d_scan_planes.p, scan_planes.data(), sizeof(DGeom) * scan_planes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_scan_spheres.p, scan_spheres.data(), sizeof(DGeom) * scan_spheres.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_scan_screen.p, scan_screen.data(), sizeof(DScreen2) * scan_screen.size(), hipMemcpyHostToDevice));
     if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
     if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
     if ((rc = s->d_screen.ensure(sizeof(DScreen2) * scr.size()))) return rc;
@@ -487,6 +523,11 @@ int upload_scene(pt_scene* s) {
     D.mat = (const DMat*)s->d_mat.p;
     D.screen = (const DScreen2*)s->d_screen.p;
     D.lights = (const int32_t*)s->d_lights.p;
+    D.scan_planes = (const DGeom*)s->d_scan_planes.p;
+    D.scan_spheres = (const DGeom*)s->d_scan_spheres.p;
+    D.scan_screen = (const DScreen2*)s->d_scan_screen.p;
+    D.n_planes = n_planes;
+    D.n_spheres = n_spheres;
     D.n_bodies = n;
     D.sphere_c1max = c1max * 1.0001f;
     D.sphere_r2max = r2max * 1.0001f;
@@ -645,6 +686,9 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_geom.release();
     s->d_mat.release();
     s->d_screen.release();
+    s->d_scan_planes.release();
+    s->d_scan_spheres.release();
+    s->d_scan_screen.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
     for (int k = 0; k < 2; ++k) {
