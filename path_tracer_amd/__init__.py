@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+# PTGPU_LIB selects another build of the same ABI (development builds with counters)
+LIB_PATH = os.environ.get("PTGPU_LIB") or os.path.join(_HERE, "libptgpu.so")
 
 SPHERE, PLANE = 0, 1
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3

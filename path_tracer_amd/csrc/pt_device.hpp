@@ -14,6 +14,38 @@ namespace ptd {
 
 #define PTD_INLINE __device__ __forceinline__
 
+// ---- optional section timing (development builds only: -DPT_PROFILE_SECTIONS) -------------
+// PT_PROF(k) times the enclosing scope with the wave's cycle counter and adds the time to a
+// per-wave LDS slot; the fused kernel flushes the slots to g_prof when it ends.  Nested scopes
+// are counted in both.  Without the macro nothing is emitted.
+#ifdef PT_PROFILE_SECTIONS
+enum {
+    kProfTotal, kProfSetup, kProfScanPlanes, kProfScanScreen, kProfScanExact, kProfShade, kProfGlass, kProfDiffuse,
+    kProfChrome, kProfNormalSphere, kProfNeePrep, kProfNeeVertex, kProfRecords, kProfN
+};
+constexpr int kProfWaves = 4;
+__shared__ long long s_prof[kProfWaves * kProfN];
+__device__ unsigned long long g_prof[kProfN];
+struct ProfScope {
+    int k;
+    long long t0;
+    PTD_INLINE ProfScope(int kk) : k(kk), t0(__builtin_amdgcn_s_memtime()) {}
+    PTD_INLINE ~ProfScope() {
+        long long dt = (long long)__builtin_amdgcn_s_memtime() - t0;
+        unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        int lane = (int)(threadIdx.x & 63);
+        if (lane == __builtin_ctzll(act)) s_prof[(threadIdx.x >> 6) * kProfN + k] += dt;
+    }
+};
+#define PT_PROF_CAT2(a, b) a##b
+#define PT_PROF_CAT(a, b) PT_PROF_CAT2(a, b)
+#define PT_PROF(k) ProfScope PT_PROF_CAT(prof_scope_, __LINE__)(k)
+#else
+#define PT_PROF(k) \
+    do {           \
+    } while (0)
+#endif
+
 constexpr int kMaxDepth = 5;  // trace() returns at n > 4: main.cpp:368
 constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
@@ -152,12 +184,19 @@ struct DScreen2 {
 struct DScene {
     const DGeom* geom;
     const DScreen2* screen;  // ceil(n/2) records
-    // Compact lists of the fused scan (body index in pad[0]): planes, then spheres padded to an
-    // even count with a record whose screen can never pass, and the spheres' paired screen records.
+    // Compact lists of the fused scan (body index in pad[0]): the planes that belong to no slab;
+    // the spheres padded to an even count with a record whose screen can never pass, and the
+    // spheres' paired screen records.
     const DGeom* scan_planes;
     const DGeom* scan_spheres;
     const DScreen2* scan_screen;
     int32_t n_planes, n_spheres;
+    // Slab of axis k (bit k of slab_mask): the two axis-aligned planes of that axis with the
+    // smallest and the largest coordinate, bodies slab_ilo[k] and slab_ihi[k].  slab_big[k] bounds
+    // |o_k| for the one-division form (see scan_slab).
+    int32_t slab_mask;
+    int32_t slab_ilo[3], slab_ihi[3];
+    double slab_lo[3], slab_hi[3], slab_big[3];
     const DMat* mat;
     const int32_t* lights;  // body indices with any emission channel >= 1 (next_event.cpp:362-367)
     const double* brdf[8];
@@ -302,46 +341,109 @@ PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t) {
 // Nearest-hit scan main.cpp:372-383: (t > 0) && (t <= mint) over the bodies in index order, i.e.
 // the smallest positive t with ties going to the larger index; `skip` is the light excluded by
 // next_event.cpp:415-419 (-1: none).  That result does not depend on the order of evaluation, so
-// the scan walks two compact lists built at upload (body index in pad[0]):
+// the scan is organised by shape (lists built at upload, body index in pad[0]):
 //  1. planes in ascending order with the reference's own `t <= mint` rule;
-//  2. spheres, two per step: the packed single-precision screen decides per wave whether either
-//     needs its exact FP64 evaluation; an exact result is merged with the explicit rule
-//     (t < mint) || (t == mint && index > hit).
+//  2. slabs: per axis, two axis-aligned planes c_lo < c_hi tested with one division (scan_slab),
+//     merged with the explicit rule (t < mint) || (t == mint && index > hit);
+//  3. spheres, two per step: the packed single-precision screen decides per wave whether either
+//     needs its exact FP64 evaluation, merged with the same explicit rule.
 // Records are read at wave-uniform addresses (scalar loads); the shape switch is a scalar branch.
-PTD_INLINE void merge_sphere(const DGeom& g, V3 o, V3 d, int skip, int& hit, double& mint) {
-    double t;
-    bool ok = scan_sphere_exact(g, o, d, t);
-    const int i = g.pad[0];
-    bool take = ok && (t > 0.0) && ((t < mint) || ((t == mint) && (i > hit))) && (i != skip);
+PTD_INLINE void merge_hit(bool ok, double t, int i, int skip, int& hit, double& mint) {
+    // bitwise on purpose: plain compares combined on the scalar unit, no divergent branches
+    const bool take = ok & (t > 0.0) & ((t < mint) | ((t == mint) & (i > hit))) & (i != skip);
     mint = take ? t : mint;
     hit = take ? i : hit;
 }
-PTD_INLINE int nearest_hit_lists(const DGeom* __restrict__ planes, int n_planes, const DGeom* __restrict__ spheres,
-                                 const DScreen2* __restrict__ screen, int n_spheres, float c1max, float r2max, V3 o,
-                                 V3 d, int skip, double& tmin) {
+// Lane masks: a compare is taken as a 64-bit wave mask (the SGPR pair v_cmp writes), combined with
+// scalar logic, and applied with v_cndmask.  Written out because the compiler otherwise
+// materialises selected booleans as 0/1 in vector registers.
+typedef unsigned long long lanemask;
+#define PTD_MASK(cond) __builtin_amdgcn_ballot_w64(cond)
+PTD_INLINE uint32_t sel32(lanemask m, uint32_t if_set, uint32_t if_clear) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+PTD_INLINE double sel64(lanemask m, double if_set, double if_clear) {
+    uint32_t lo = sel32(m, (uint32_t)__double2loint(if_set), (uint32_t)__double2loint(if_clear));
+    uint32_t hi = sel32(m, (uint32_t)__double2hiint(if_set), (uint32_t)__double2hiint(if_clear));
+    return __hiloint2double((int)hi, (int)lo);
+}
+// (t > 0) && ((t < mint) || (t == mint && i > hit)) && (i != skip), within `valid`
+PTD_INLINE void merge_masked(lanemask valid, double t, int i, int skip, int& hit, double& mint) {
+    const lanemask take = valid & PTD_MASK(t > 0.0) & (PTD_MASK(t < mint) | (PTD_MASK(t == mint) & PTD_MASK(i > hit))) &
+                          PTD_MASK(i != skip);
+    mint = sel64(take, t, mint);
+    hit = (int)sel32(take, (uint32_t)i, (uint32_t)hit);
+}
+
+// Two parallel axis-aligned planes, n_lo = c_lo - o_k < n_hi = c_hi - o_k, share the divisor d_k.
+// The quotient that can win the scan is the smallest positive one: for d_k > 0 that of n_lo when
+// n_lo > 0, else that of n_hi; for d_k < 0 that of n_hi when n_hi < 0, else that of n_lo.  Only
+// that division is made.  The other quotient matters in two cases, both only when the two have
+// the same sign (`both`): the chosen plane is the excluded light, or the two quotients could
+// round to the same value (excluded by |o_k| < big, which keeps n_hi - n_lo above 2^-41 |n|).
+// Then (wave-uniform, rare) the second quotient is formed and merged as well.
+PTD_INLINE void scan_slab(double lo, double hi, double big, int ilo, int ihi, double ok_, double dk, int skip, int& hit,
+                          double& mint) {
+    const double n_lo = lo - ok_, n_hi = hi - ok_;
+    const lanemask pos = PTD_MASK(dk > 0.0), a = PTD_MASK(n_lo > 0.0), b = PTD_MASK(n_hi < 0.0);
+    const lanemask pick_lo = (pos & a) | ~(pos | b);
+    const lanemask both = (pos & a) | (~pos & b);
+    const lanemask valid = PTD_MASK(!(__builtin_fabs(dk) < 0.00001));  // == !((dk > -1e-5) && (dk < 1e-5))
+    const int i = (int)sel32(pick_lo, (uint32_t)ilo, (uint32_t)ihi);
+    const double t = sel64(pick_lo, n_lo, n_hi) / dk;
+    merge_masked(valid, t, i, skip, hit, mint);
+    const lanemask second = both & (PTD_MASK(i == skip) | ~PTD_MASK(__builtin_fabs(ok_) < big));
+    if (second != 0) {
+        const double t2 = sel64(pick_lo, n_hi, n_lo) / dk;
+        merge_masked(valid, t2, (int)sel32(pick_lo, (uint32_t)ihi, (uint32_t)ilo), skip, hit, mint);
+    }
+}
+PTD_INLINE void merge_sphere(const DGeom& g, V3 o, V3 d, int skip, int& hit, double& mint) {
+    PT_PROF(kProfScanExact);
+    double t;
+    bool ok = scan_sphere_exact(g, o, d, t);
+    merge_hit(ok, t, g.pad[0], skip, hit, mint);
+}
+PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ planes, const DGeom* __restrict__ spheres,
+                                 const DScreen2* __restrict__ screen, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    for (int k = 0; k < n_planes; ++k) {
-        DGeom g = planes[k];
-        double t;
-        bool ok;
-        switch (g.shape) {
-            case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
-            case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
-            case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
-            default: ok = scan_plane(g, o, d, t); break;
+    {
+        PT_PROF(kProfScanPlanes);
+        const int n_planes = S.n_planes;
+        for (int k = 0; k < n_planes; ++k) {
+            const DGeom g = planes[k];
+            double t;
+            bool ok;
+            switch (g.shape) {
+                case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
+                case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
+                case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
+                default: ok = scan_plane(g, o, d, t); break;
+            }
+            const int i = g.pad[0];
+            bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
+            mint = take ? t : mint;
+            hit = take ? i : hit;
         }
-        const int i = g.pad[0];
-        bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
-        mint = take ? t : mint;
-        hit = take ? i : hit;
+        if (S.slab_mask & 1)
+            scan_slab(S.slab_lo[0], S.slab_hi[0], S.slab_big[0], S.slab_ilo[0], S.slab_ihi[0], o.x, d.x, skip, hit, mint);
+        if (S.slab_mask & 2)
+            scan_slab(S.slab_lo[1], S.slab_hi[1], S.slab_big[1], S.slab_ilo[1], S.slab_ihi[1], o.y, d.y, skip, hit, mint);
+        if (S.slab_mask & 4)
+            scan_slab(S.slab_lo[2], S.slab_hi[2], S.slab_big[2], S.slab_ilo[2], S.slab_ihi[2], o.z, d.z, skip, hit, mint);
     }
+    const int n_spheres = S.n_spheres;
     if (n_spheres > 0) {
-        const RayF rf = make_rayf(o, d, c1max, r2max);
+        PT_PROF(kProfScanScreen);
+        const RayF rf = make_rayf(o, d, S.sphere_c1max, S.sphere_r2max);
         const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
         const float e_disc = rf.e_disc, e_b = rf.e_b;
         for (int k = 0; 2 * k < n_spheres; ++k) {
-            const unsigned m = sphere_possible2(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, screen[k]);
+            const DScreen2 sc = screen[k];
+            const unsigned m = sphere_possible2(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sc);
             if (__builtin_amdgcn_ballot_w64((m & 1u) != 0) != 0) merge_sphere(spheres[2 * k], o, d, skip, hit, mint);
             if (__builtin_amdgcn_ballot_w64((m & 2u) != 0) != 0) merge_sphere(spheres[2 * k + 1], o, d, skip, hit, mint);
         }
@@ -350,8 +452,7 @@ PTD_INLINE int nearest_hit_lists(const DGeom* __restrict__ planes, int n_planes,
     return hit;
 }
 PTD_INLINE int nearest_hit(const DScene& S, V3 o, V3 d, int skip, double& tmin) {
-    return nearest_hit_lists(S.scan_planes, S.n_planes, S.scan_spheres, S.scan_screen, S.n_spheres, S.sphere_c1max,
-                             S.sphere_r2max, o, d, skip, tmin);
+    return nearest_hit_lists(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, skip, tmin);
 }
 
 // ---- materials -------------------------------------------------------------------------
@@ -403,14 +504,22 @@ PTD_INLINE V3 bounce_glass(Draws& dr, V3 d, V3 n, double ior, double eta, double
 }
 
 PTD_INLINE V3 bounce(const DMat& m, Draws& dr, V3 d, V3 n) {
-    if (m.material == kChrome) return bounce_chrome(d, n);
-    if (m.material == kGlass) return bounce_glass(dr, d, n, m.ior, m.eta, m.refl);
+    if (m.material == kChrome) {
+        PT_PROF(kProfChrome);
+        return bounce_chrome(d, n);
+    }
+    if (m.material == kGlass) {
+        PT_PROF(kProfGlass);
+        return bounce_glass(dr, d, n, m.ior, m.eta, m.refl);
+    }
+    PT_PROF(kProfDiffuse);
     return random_in_hemisphere(dr, n);  // Material::bounce main.cpp:250-253
 }
 
 // getNormal: Plane main.cpp:192-194, Sphere main.cpp:224-226
 PTD_INLINE V3 shape_normal(const DGeom& g, V3 point) {
     if (g.shape != kSphere) return mk(g.nx, g.ny, g.nz);
+    PT_PROF(kProfNormalSphere);
     return normalize(sub(point, mk(g.cx, g.cy, g.cz)));
 }
 
@@ -555,6 +664,7 @@ struct PathResult {
 // bounce, then the hit point moved by the factor 1 +- 1e-7 along the ray.  Updates the ray in
 // place and returns the recorded (offset) point.
 PTD_INLINE V3 shade_hit(const DGeom& g, const DMat& m, Draws& dr, V3& o, V3& d, double mint) {
+    PT_PROF(kProfShade);
     V3 point = add(o, muls(d, mint));
     V3 normal = shape_normal(g, point);
     V3 dir = bounce(m, dr, d, normal);
@@ -652,6 +762,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         int hit = nearest_hit(S, o, d, -1, mint);
         if (hit < 0) break;
         V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
+        PT_PROF(kProfRecords);
         rec.put(n, point, hit);
     }
     PathResult R;
@@ -671,13 +782,19 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
     LightTerm T = light_term(S, light);
 #pragma unroll 1
     for (int gi = n - 1; gi >= 0; --gi) {
-        V3 P = rec.point(gi);
-        int target = rec.body(gi);
-        V3 bd = normalize(sub(P, T.lc));
+        V3 P, bd;
+        int target;
+        {
+            PT_PROF(kProfNeePrep);
+            P = rec.point(gi);
+            target = rec.body(gi);
+            bd = normalize(sub(P, T.lc));
+        }
         double mint;
         int hit = nearest_hit(S, T.lc, bd, light, mint);
         if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
+        PT_PROF(kProfNeeVertex);
         V3 next_point = campt;
         if (gi >= 1) next_point = rec.point(gi - 1);
         L = nee_vertex<MEASURED, ELIDE>(S, geom[hit], mat[hit], dr, T, P, bd, next_point, L);

@@ -152,7 +152,16 @@ __global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Pa
     const size_t j = (size_t)blockIdx.x * kBlock + tid;
     double* out = samples + (size_t)b * 3 * sample_stride + j;
     V3 rgb = mk(0.0, 0.0, 0.0);
+#ifdef PT_PROFILE_SECTIONS
+    if (tid < kProfWaves * kProfN) s_prof[tid] = 0;
+    __syncthreads();
+    {
+    PT_PROF(kProfTotal);
+#endif
     if (slot >= 0 && slot < npix[b]) {
+#ifdef PT_PROFILE_SECTIONS
+        long long t_setup = __builtin_amdgcn_s_memtime();
+#endif
         const int32_t* rs = row_start + (size_t)b * (H + 1);
         int r = slot / W;
         while (slot >= rs[r + 1]) r++;
@@ -171,9 +180,18 @@ __global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Pa
         rec.bod = s_bod;
         rec.stride = kBlock;
         rec.tid = tid;
+#ifdef PT_PROFILE_SECTIONS
+        if ((tid & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+            s_prof[(tid >> 6) * kProfN + kProfSetup] += (long long)__builtin_amdgcn_s_memtime() - t_setup;
+#endif
         PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
         rgb = R.rgb;
     }
+#ifdef PT_PROFILE_SECTIONS
+    }
+    __syncthreads();
+    if (tid < kProfWaves * kProfN) atomicAdd(&g_prof[tid % kProfN], (unsigned long long)s_prof[tid]);
+#endif
     out[0] = rgb.x;
     out[sample_stride] = rgb.y;
     out[2 * sample_stride] = rgb.z;
@@ -472,13 +490,42 @@ int upload_scene(pt_scene* s) {
         m.brdf_id = b.brdf_id;
         mat[i] = m;
     }
-    // Compact lists of the fused scan: planes and spheres in ascending body order, body index in
-    // pad[0]; an odd sphere count is padded with a record whose screen never passes (r2 = -inf).
+    // Compact lists of the fused scan (body index in pad[0]), each in ascending body order: the
+    // planes outside the slabs and the spheres; an odd sphere count is padded with a record whose
+    // screen never passes (r2 = -inf).  A slab joins, per axis, the two axis-aligned planes with
+    // the smallest and the largest coordinate, provided the bound slab_big is usable.
     std::vector<DGeom> scan_planes, scan_spheres;
+    std::vector<char> in_slab(n, 0);
+    DScene& D = s->ds;
+    memset(&D, 0, sizeof D);
+    for (int axis = 0; axis < 3; ++axis) {
+        int lo = -1, hi = -1;
+        auto coord = [&](int i) { return axis == 0 ? geom[i].cx : axis == 1 ? geom[i].cy : geom[i].cz; };
+        for (int i = 0; i < n; ++i) {
+            if (geom[i].shape != kPlaneX + axis) continue;
+            if (lo < 0 || coord(i) < coord(lo)) lo = i;
+            if (hi < 0 || coord(i) > coord(hi)) hi = i;
+        }
+        if (lo < 0 || !(coord(lo) < coord(hi))) continue;
+        // |o_k| < big  =>  |c - o_k| < 2^40 (c_hi - c_lo) for both planes
+        const double big = std::ldexp(coord(hi) - coord(lo), 40) - std::max(std::fabs(coord(lo)), std::fabs(coord(hi)));
+        if (!(big > 0.0) || !std::isfinite(big)) continue;
+        D.slab_big[axis] = big;
+        D.slab_mask |= 1 << axis;
+        D.slab_lo[axis] = coord(lo);
+        D.slab_hi[axis] = coord(hi);
+        D.slab_ilo[axis] = lo;
+        D.slab_ihi[axis] = hi;
+        in_slab[lo] = in_slab[hi] = 1;
+    }
     for (int i = 0; i < n; ++i) {
         DGeom g = geom[i];
         g.pad[0] = i;
-        (g.shape == kSphere ? scan_spheres : scan_planes).push_back(g);
+        if (g.shape == kSphere) {
+            scan_spheres.push_back(g);
+        } else {
+            if (!in_slab[i]) scan_planes.push_back(g);
+        }
     }
     const int n_planes = (int)scan_planes.size(), n_spheres = (int)scan_spheres.size();
     if (n_spheres & 1) {
@@ -517,8 +564,6 @@ int upload_scene(pt_scene* s) {
     HIP_TRY(hipMemcpy(s->d_screen.p, scr.data(), sizeof(DScreen2) * scr.size(), hipMemcpyHostToDevice));
     if (!s->lights.empty())
         HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), sizeof(int32_t) * s->lights.size(), hipMemcpyHostToDevice));
-    DScene& D = s->ds;
-    memset(&D, 0, sizeof D);
     D.geom = (const DGeom*)s->d_geom.p;
     D.mat = (const DMat*)s->d_mat.p;
     D.screen = (const DScreen2*)s->d_screen.p;
@@ -1055,3 +1100,15 @@ int pt_brdf_lookup(pt_scene* s, int id, const double* angles4, int n, double* rg
 }
 
 }  // extern "C"
+
+#ifdef PT_PROFILE_SECTIONS
+// Development only: cycles per section summed over waves since the last call (and reset).
+extern "C" int pt_prof_read(unsigned long long* out, int n) {
+    unsigned long long h[ptd::kProfN] = {};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_prof), sizeof h) != hipSuccess) return -1;
+    for (int k = 0; k < n && k < ptd::kProfN; ++k) out[k] = h[k];
+    unsigned long long z[ptd::kProfN] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_prof), z, sizeof z) != hipSuccess) return -1;
+    return ptd::kProfN;
+}
+#endif
