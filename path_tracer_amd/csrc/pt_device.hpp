@@ -691,40 +691,39 @@ PTD_INLINE int pick_light(const DScene& S, Draws& dr) {
     return S.lights[li];
 }
 
-struct LightTerm {
-    V3 lc;     // origin of the shadow rays
-    V3 lterm;  // emission * colour
-    bool direct_is_zero;
-};
-PTD_INLINE LightTerm light_term(const DScene& S, int light) {
-    LightTerm T;
-    DMat lm = S.mat[light];
-    // light->shape->center through a Shape* is the never-assigned base member (0,0,0)
-    // (next_event.cpp:167,406-407) unless the scene asks for the real centre.
-    T.lc = mk(0.0, 0.0, 0.0);
+// Origin of the shadow rays towards `light`: light->shape->center through a Shape* is the
+// never-assigned base member (0,0,0) (next_event.cpp:167,406-407) unless the scene asks for the
+// real centre.
+PTD_INLINE V3 light_origin(const DScene& S, int light) {
+    V3 lc = mk(0.0, 0.0, 0.0);
     if (S.flags & 1u) {
         DGeom lg = S.geom[light];
-        T.lc = mk(lg.cx, lg.cy, lg.cz);
+        lc = mk(lg.cx, lg.cy, lg.cz);
     }
-    T.lterm = mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
-    // When emission*colour of the chosen light is exactly zero (every light of the reference's own
-    // scenes has colour 0, next_event.cpp:660,674), (Le*Lc)*flux is a zero of known sign whatever
-    // the finite flux is, and nothing after the NEE loop reads the random stream: the fake-BRDF
-    // bounce that produces flux is dead and may be skipped.  Results are bit-identical.
-    T.direct_is_zero = (T.lterm.x == 0.0) && (T.lterm.y == 0.0) && (T.lterm.z == 0.0);
-    return T;
+    return lc;
+}
+// emission * colour of the light (next_event.cpp:452).  When it is exactly zero (every light of
+// the reference's own scenes has colour 0, next_event.cpp:660,674), (Le*Lc)*flux is a zero of
+// known sign whatever the finite flux is, and nothing after the NEE loop reads the random stream:
+// the fake-BRDF bounce that produces flux is dead and may be skipped.  Results are bit-identical.
+// The term is re-read per lit vertex instead of being kept in registers across the shadow scans.
+PTD_INLINE V3 light_term(const DScene& S, int light) {
+    DMat lm = S.mat[light];
+    return mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
 }
 
 // One lit vertex of the NEE loop (next_event.cpp:442-463): L = ((L + (Le*Lc)*flux) * c) + e.
 // `bd` is the shadow-ray direction, `next_point` the previous vertex (or the camera-plane point
 // for vertex 0, next_event.cpp:443-447).
 template <bool MEASURED, bool ELIDE>
-PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& dr, const LightTerm& T, V3 P, V3 bd,
+PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& dr, int light, V3 P, V3 bd,
                          V3 next_point, V3 L) {
     V3 scale;
+    const V3 lterm = light_term(S, light);
+    const bool direct_is_zero = (lterm.x == 0.0) & (lterm.y == 0.0) & (lterm.z == 0.0);
     // flux is finite for diffuse and chrome, and for glass with ior >= 1
-    if (ELIDE && T.direct_is_zero && m.material != kMeasured && (m.material != kGlass || m.ior >= 1.0)) {
-        scale = muls(T.lterm, 0.0);
+    if (ELIDE && direct_is_zero && m.material != kMeasured && (m.material != kGlass || m.ior >= 1.0)) {
+        scale = muls(lterm, 0.0);
         return add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
     }
     V3 nprime = normalize(sub(next_point, P));
@@ -735,11 +734,11 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
         vector_to_spherical(bd, ti, pi);
         vector_to_spherical(nprime, to, po);
         V3 f = brdf_lookup(S.brdf[m.brdf_id], ti, pi, to, po, nullptr);
-        scale = mul(T.lterm, f);
+        scale = mul(lterm, f);
     } else {
         V3 light_brdf = bounce(m, dr, bd, nprime);
         double light_flux = fabs(dot(light_brdf, shape_normal(g, P)));
-        scale = muls(T.lterm, light_flux);
+        scale = muls(lterm, light_flux);
     }
     return add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
 }
@@ -778,26 +777,26 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         R.rgb = L;
         return R;
     }
-    int light = pick_light(S, dr);
-    LightTerm T = light_term(S, light);
+    const int light = pick_light(S, dr);
 #pragma unroll 1
     for (int gi = n - 1; gi >= 0; --gi) {
-        V3 P, bd;
+        V3 P, bd, lc;
         int target;
         {
             PT_PROF(kProfNeePrep);
             P = rec.point(gi);
             target = rec.body(gi);
-            bd = normalize(sub(P, T.lc));
+            lc = light_origin(S, light);
+            bd = normalize(sub(P, lc));
         }
         double mint;
-        int hit = nearest_hit(S, T.lc, bd, light, mint);
+        int hit = nearest_hit(S, lc, bd, light, mint);
         if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
         PT_PROF(kProfNeeVertex);
         V3 next_point = campt;
         if (gi >= 1) next_point = rec.point(gi - 1);
-        L = nee_vertex<MEASURED, ELIDE>(S, geom[hit], mat[hit], dr, T, P, bd, next_point, L);
+        L = nee_vertex<MEASURED, ELIDE>(S, geom[hit], mat[hit], dr, light, P, bd, next_point, L);
     }
     R.rgb = L;
     return R;

@@ -206,10 +206,10 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int
             d = load3(W.ray, W.cap, p, 3);
         } else {
             const int light = W.light[p];
-            LightTerm T = light_term(S, light);
+            const V3 lc = light_origin(S, light);
             V3 Pt = load3(W.pts, W.cap, p, gi * 3);
-            o = T.lc;
-            d = normalize(sub(Pt, T.lc));  // next_event.cpp:405-407
+            o = lc;
+            d = normalize(sub(Pt, lc));  // next_event.cpp:405-407
             skip = light;
         }
     }
@@ -272,9 +272,9 @@ __global__ void __launch_bounds__(kWfBlock, MEASURED ? 2 : 4) k_wf_nee(DScene S,
     const int hit = W.hit[p];
     if (hit != W.bod[(size_t)gi * W.cap + p]) return;  // occluded: vertex skipped, next_event.cpp:428-430
     const int light = W.light[p];
-    LightTerm T = light_term(S, light);
+    const V3 lc = light_origin(S, light);
     V3 Pt = load3(W.pts, W.cap, p, gi * 3);
-    V3 bd = normalize(sub(Pt, T.lc));
+    V3 bd = normalize(sub(Pt, lc));
     V3 next_point;
     if (gi >= 1)
         next_point = load3(W.pts, W.cap, p, (gi - 1) * 3);
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(kWfBlock, MEASURED ? 2 : 4) k_wf_nee(DScene S,
     dr.rng = load_rng(W, p);
     dr.count = 0;
     V3 L = load3(W.L, W.cap, p, 0);
-    L = nee_vertex<MEASURED, ELIDE>(S, S.geom[hit], S.mat[hit], dr, T, Pt, bd, next_point, L);
+    L = nee_vertex<MEASURED, ELIDE>(S, S.geom[hit], S.mat[hit], dr, light, Pt, bd, next_point, L);
     store3(W.L, W.cap, p, 0, L);
     store_rng(W, p, dr.rng);
 }
