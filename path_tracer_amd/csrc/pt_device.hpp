@@ -169,7 +169,8 @@ struct DMat {  // 96 bytes
     double eta;  // 1.0 / ior (Glass::bounce main.cpp:291)
     int32_t material;
     int32_t brdf_id;
-    int32_t pad[4];
+    int32_t emits;  // any emission channel != 0
+    int32_t pad[3];
 };
 
 // Screening records of the LDS-tiled scan: sphere centre and radius^2 in float, two consecutive
@@ -207,6 +208,7 @@ struct DScene {
     int32_t width, height;
     int32_t estimator;
     uint32_t flags;
+    int32_t nee_emission_only;  // see trace_path_nee_compact
     uint64_t seed;
     // Camera (main.cpp:144-152): xd = topright - topleft, yd = bottomleft - topleft
     double cam_o[3], cam_tl[3], cam_xd[3], cam_yd[3];
@@ -646,6 +648,11 @@ struct Records {
         return mk(pts[(k * 3 + 0) * stride + tid], pts[(k * 3 + 1) * stride + tid], pts[(k * 3 + 2) * stride + tid]);
     }
     PTD_INLINE int body(int k) const { return bod[k * stride + tid]; }
+    // records of another thread of the block
+    PTD_INLINE V3 point_of(int k, int t) const {
+        return mk(pts[(k * 3 + 0) * stride + t], pts[(k * 3 + 1) * stride + t], pts[(k * 3 + 2) * stride + t]);
+    }
+    PTD_INLINE int body_of(int k, int t) const { return bod[k * stride + t]; }
 };
 
 struct PathResult {
@@ -800,6 +807,103 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
     }
     R.rgb = L;
     return R;
+}
+
+// NEE sample for scenes whose direct term is dead for every light and every material
+// (DScene::nee_emission_only: emission*colour of each light is exactly zero, no measured material,
+// every glass ior >= 1, all colours and emissions finite).  The pixel value is then the recurrence
+// L = L*c + e over the lit vertices, deepest first, starting from 0: vertices deeper than the
+// deepest emitting one leave L at zero whether they are lit or not, so their shadow scans are not
+// needed.  The remaining (lane, vertex) shadow tasks of a wave are dealt to its 64 lanes, 64 at a
+// time: an owner publishes (lane, vertex, light) in a 16-bit LDS slot at the task's rank, lane q
+// takes slot q, reads the vertex from the owner's LDS records, runs the shadow scan, and the
+// owners pick their visibility bits out of the ballot.  Every lane of the wave must call this
+// (`valid` false for lanes without a pixel).  Sample values equal trace_path<kEstNEE,false,true>'s
+// except that a zero result may differ in sign, which no sum of samples can observe.
+PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, double x, double y, const Records& rec,
+                                     uint16_t* __restrict__ wave_slots) {
+    int n = 0, need = 0, light = 0;
+    if (valid) {
+        V3 o = ld3(S.cam_o);
+        V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157
+#pragma unroll 1
+        for (; n < kMaxDepth; ++n) {
+            double mint;
+            int hit = nearest_hit(S, o, d, -1, mint);
+            if (hit < 0) break;
+            const DMat& m = S.mat[hit];
+            V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);
+            rec.put(n, point, hit);
+            if (m.emits) need = n + 1;
+        }
+        light = pick_light(S, dr);
+    }
+    const int lane = rec.tid & 63;
+    const int wave_tid0 = rec.tid & ~63;
+    lanemask owners[kMaxDepth];
+    int first[kMaxDepth + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int g = 0; g < kMaxDepth; ++g) {
+        owners[g] = PTD_MASK(need > g);
+        first[g + 1] = first[g] + __builtin_popcountll(owners[g]);
+    }
+    const int total = first[kMaxDepth];
+    unsigned vis = 0;
+#pragma unroll 1
+    for (int base = 0; base < total; base += 64) {
+        PT_PROF(kProfNeeVertex);
+#pragma unroll
+        for (int g = 0; g < kMaxDepth; ++g) {
+            if (first[g + 1] > base && first[g] < base + 64) {
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(owners[g] >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)owners[g], 0u));
+                const int q = first[g] + below - base;
+                if ((need > g) & ((unsigned)q < 64u)) wave_slots[q] = (uint16_t)(lane | (g << 6) | (light << 9));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool lit = false;
+        if (base + lane < total) {
+            const unsigned slot = wave_slots[lane];
+            const int g = (int)((slot >> 6) & 7u), lt = (int)(slot >> 9);
+            const int owner = wave_tid0 | (int)(slot & 63u);
+            V3 P, bd, lc;
+            {
+                PT_PROF(kProfNeePrep);
+                P = rec.point_of(g, owner);
+                lc = light_origin(S, lt);
+                bd = normalize(sub(P, lc));  // next_event.cpp:405-407
+            }
+            double mint;
+            int hit = nearest_hit(S, lc, bd, lt, mint);
+            lit = hit == rec.body_of(g, owner);  // next_event.cpp:428-430
+        }
+        const lanemask lit_mask = PTD_MASK(lit);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < kMaxDepth; ++g) {
+            if (first[g + 1] > base && first[g] < base + 64) {
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(owners[g] >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)owners[g], 0u));
+                const int q = first[g] + below - base;
+                if ((need > g) & ((unsigned)q < 64u)) vis |= (unsigned)((lit_mask >> q) & 1ull) << g;
+            }
+        }
+    }
+    V3 L = mk(0.0, 0.0, 0.0);
+    if (need > 0) {
+        const V3 scale = muls(light_term(S, light), 0.0);
+#pragma unroll 1
+        for (int g = need - 1; g >= 0; --g) {
+            if (!((vis >> g) & 1u)) continue;
+            const DMat& m = S.mat[rec.body(g)];
+            L = add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));  // next_event.cpp:452-462
+        }
+    }
+    return L;
 }
 
 }  // namespace ptd

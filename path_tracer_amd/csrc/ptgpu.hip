@@ -138,13 +138,16 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 // (5 x 32000 B) just fit the 160 KiB of a CU and the register file allows 96 VGPRs per lane; the
 // estimator is latency-bound on FP64 dependency chains, and the fifth wave buys ~8 %.  The variant
 // with the measured-BRDF lookup (sin/cos/acos/atan2 expansions) needs ~240 registers and runs at 2.
-template <int EST, bool MEASURED>
+// COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
+// shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.
+template <int EST, bool MEASURED, bool COMPACT = false>
 __global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
     __shared__ double s_pts[kMaxDepth * 3 * kBlock];
     __shared__ int8_t s_bod[kMaxDepth * kBlock];
+    __shared__ uint16_t s_slots[COMPACT ? kBlock : 1];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int W = S.width, H = S.height;
@@ -158,7 +161,12 @@ __global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Pa
     {
     PT_PROF(kProfTotal);
 #endif
-    if (slot >= 0 && slot < npix[b]) {
+    const bool valid = slot >= 0 && slot < npix[b];
+    double x = 0.0, y = 0.0;
+    Draws dr;
+    dr.rng.s0 = dr.rng.s1 = dr.rng.s2 = dr.rng.s3 = 0;
+    dr.count = 0;
+    if (valid) {
 #ifdef PT_PROFILE_SECTIONS
         long long t_setup = __builtin_amdgcn_s_memtime();
 #endif
@@ -169,21 +177,23 @@ __global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Pa
         // x of column c: the row's running sum x += xstep (main.cpp:355-357), continued from the
         // stored value at the previous multiple of 32
         const int CK = (W + kXStride - 1) / kXStride;
-        double x = xs[((size_t)b * H + r) * CK + c / kXStride];
+        x = xs[((size_t)b * H + r) * CK + c / kXStride];
         for (int i = c & (kXStride - 1); i > 0; --i) x += xstep;
-        double y = ys[(size_t)b * H + r];
-        Draws dr;
+        y = ys[(size_t)b * H + r];
         dr.rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
-        dr.count = 0;
-        Records rec;
-        rec.pts = s_pts;
-        rec.bod = s_bod;
-        rec.stride = kBlock;
-        rec.tid = tid;
 #ifdef PT_PROFILE_SECTIONS
         if ((tid & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
             s_prof[(tid >> 6) * kProfN + kProfSetup] += (long long)__builtin_amdgcn_s_memtime() - t_setup;
 #endif
+    }
+    Records rec;
+    rec.pts = s_pts;
+    rec.bod = s_bod;
+    rec.stride = kBlock;
+    rec.tid = tid;
+    if (COMPACT) {
+        rgb = trace_path_nee_compact(S, dr, valid, x, y, rec, s_slots + (tid & ~63));
+    } else if (valid) {
         PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
         rgb = R.rgb;
     }
@@ -431,6 +441,8 @@ int ensure_render_buffers(pt_scene* s) {
     return PT_OK;
 }
 
+constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
+
 int upload_scene(pt_scene* s) {
     const int n = (int)s->bodies.size();
     std::vector<DGeom> geom(n);
@@ -488,6 +500,7 @@ int upload_scene(pt_scene* s) {
         m.eta = 1.0 / b.ior;
         m.material = b.material;
         m.brdf_id = b.brdf_id;
+        m.emits = (b.emission[0] != 0.0) || (b.emission[1] != 0.0) || (b.emission[2] != 0.0);
         mat[i] = m;
     }
     // Compact lists of the fused scan (body index in pad[0]), each in ascending body order: the
@@ -581,6 +594,19 @@ int upload_scene(pt_scene* s) {
     D.height = s->height;
     D.estimator = s->estimator;
     D.flags = s->flags;
+    // The direct term of next-event estimation is dead for the whole scene when emission*colour of
+    // every light is exactly zero and the flux it would be scaled by is finite for every material
+    // (no measured tables, glass ior >= 1, finite colours); light indices must fit 7 bits.
+    bool dead = s->estimator == PT_EST_NEE && n <= kMaxBodiesFused && s->lights.size() >= 2;
+    for (int i = 0; i < n && dead; ++i) {
+        const pt_body& b = s->bodies[i];
+        for (int k = 0; k < 3; ++k) dead = dead && std::isfinite(b.color[k]) && std::isfinite(b.emission[k]);
+        if (b.material == PT_MEASURED) dead = false;
+        if (b.material == PT_GLASS && !(b.ior >= 1.0)) dead = false;
+    }
+    for (int li : s->lights)
+        for (int k = 0; k < 3; ++k) dead = dead && (s->bodies[li].emission[k] * s->bodies[li].color[k] == 0.0);
+    D.nee_emission_only = dead ? 1 : 0;
     D.seed = s->seed;
     for (int k = 0; k < 3; ++k) {
         D.cam_o[k] = s->camera.origin[k];
@@ -591,7 +617,6 @@ int upload_scene(pt_scene* s) {
     return PT_OK;
 }
 
-constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
 
 int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
@@ -873,7 +898,9 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         if (use_wavefront) {
             int rcw = render_wavefront(s, st, it0, B, xs, ys, rs, npix, samples, J);
             if (rcw) return rcw;
-        } else if (s->estimator == PT_EST_NEE && s->has_measured)
+        } else if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
+            hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        else if (s->estimator == PT_EST_NEE && s->has_measured)
             hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
         else if (s->estimator == PT_EST_NEE)
             hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
