@@ -127,6 +127,9 @@ def main():
         lights = [i for i in range(desc.body_count) if max(desc.bodies[i].emission) >= 1.0]
         flop_per_path += 5.0 * (scan - (19.0 if desc.bodies[lights[-1]].shape == pt.SPHERE else 14.0))
         rays_per_path = 10
+    wavefront = args.pipeline == "wavefront" or (args.pipeline != "fused" and desc.body_count > 127)
+    kernel_name = "k_wf_* stages (wavefront pipeline)" if wavefront else (
+        "k_trace<NEE>" if desc.estimator == pt.EST_NEE else "k_trace<PT>")
     accum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -197,7 +200,12 @@ def main():
                 "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                 "frac_of_no_fma_ceiling": achieved / (FP64_VALU_PEAK_TFLOPS / 2),
                 "traffic": traffic_bytes_per_launch(paths_per_launch),
-                "kernel": "k_trace<NEE>",
+                "hbm_view": {
+                    "algorithmic_GBps": paths_per_launch * 24.0 / (avg_ms * 1e-3) / 1e9,
+                    "peak_GBps": 8000.0,
+                    "note": "24 B of FP64 sample per path; the kernel is FP64-VALU bound, not HBM bound",
+                },
+                "kernel": kernel_name,
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
                 "flop_per_path": flop_per_path,
