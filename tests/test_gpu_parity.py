@@ -325,3 +325,80 @@ def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
         with open(out, "rb") as f:
             assert f.read() == port.save_ppm(total, iters, W, H)
         r.close()
+
+
+def scene_with_extra_planes(name, W, H, seed):
+    """The reference scene plus axis-aligned planes that stress the slab form of the scan: a plane
+    coincident with the left wall (a tie between bodies), a third x plane inside the box, a second
+    emitting z plane above the top light and a duplicate of the back wall with the opposite normal."""
+    d = pt.preset(name, W, H, seed=seed)
+    n = d.body_count
+    extra = [(8, None), (8, (0.5, 0.0, 0.0)), (10, (0.0, 0.0, 3.0)), (7, "flip")]  # 7 back, 8 left, 10 top light
+    bodies = (pt.Body * (n + len(extra)))()
+    for i in range(n):
+        bodies[i] = d.bodies[i]
+    for k, (src, change) in enumerate(extra):
+        b = pt.Body.from_buffer_copy(d.bodies[src])
+        if change == "flip":
+            for c in range(3):
+                b.normal[c] = -b.normal[c]
+        elif change is not None:
+            for c in range(3):
+                b.center[c] = change[c]
+        bodies[n + k] = b
+    d.bodies = bodies
+    d.body_count = n + len(extra)
+    d._keep = bodies
+    return d
+
+
+def edge_rays(rng, n):
+    """Origins inside, outside, exactly on and astronomically far from the walls; directions with
+    exact zeros, negative zeros and components below the parallel threshold."""
+    o = np.stack([rng.uniform(-6, 6, n), rng.uniform(-8, 9, n), rng.uniform(-3, 6, n)], axis=1)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = np.arange(n)
+    walls = [(0, -1.9), (0, 1.9), (0, 0.5), (1, 4.5), (1, -2.5), (2, -0.5), (2, 2.5), (2, 3.0)]
+    for j, (axis, c) in enumerate(walls):
+        o[k % 23 == j, axis] = c  # origin exactly on a plane
+    o[k % 23 == 9] *= 1e15
+    o[k % 23 == 10, 0] = 1e22
+    o[k % 23 == 11, 2] = -3e300
+    d[k % 19 == 0, 0] = 0.0
+    d[k % 19 == 1, 1] = -0.0
+    d[k % 19 == 2, 2] = 3e-6  # inside the +-1e-5 parallel band
+    d[k % 19 == 3, 0] = -9.99e-6
+    d[k % 19 == 4] = [0.0, 0.0, 1.0]
+    d[k % 19 == 5] = [-1.0, 0.0, 0.0]
+    return np.concatenate([o, d], axis=1)
+
+
+@pytest.mark.parametrize("name", ["nee15", "main32"])
+def test_slab_scan_edge_cases(port, name):
+    rng = np.random.default_rng(77)
+    rays = edge_rays(rng, 60_000)
+    for desc in (pt.preset(name, 16, 16), scene_with_extra_planes(name, 16, 16, 1)):
+        r = pt.Renderer(desc)
+        s = oracle_scene(port, r, 16, 16, 1)
+        nb = desc.body_count
+        for skip in [-1] + list(range(6, nb)):  # every plane (and light) as the excluded body
+            idx, t = r.intersect_batch(rays, skip=skip)
+            _, idx0, t0 = port.intersect(s, rays, skip=skip)
+            assert np.array_equal(idx, idx0), (name, nb, skip)
+            assert same_bits(t, t0), (name, nb, skip)
+        r.close()
+
+
+@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 70, 41, 5), ("main32", 37, 29, 4)])
+def test_frames_with_extra_planes(port, name, W, H, n_it):
+    # several emitters, a light inside a slab, coincident planes, image sizes that leave partial waves
+    r = pt.Renderer(scene_with_extra_planes(name, W, H, 123))
+    s = oracle_scene(port, r, W, H, 123)
+    want, _ = port.render(s, MODE_PIXEL, 1, n_it)
+    assert same_bits(r.render(1, n_it), want)
+    r.set_partition(1, 3)
+    part = r.render(1, n_it)
+    r.set_partition(0, 1)
+    assert np.count_nonzero(part) > 0 and same_bits(part[part != 0], want[part != 0])
+    r.close()
