@@ -12,7 +12,8 @@
 //
 // A path that leaves the scene is not pushed to the next queue, so later stages run on dense
 // waves only (wave64 ballot + one atomic per wave).  Queue d+1 holds the paths with more than d
-// recorded vertices; the NEE stages reuse those queues deepest first.  The arithmetic of every
+// recorded vertices; k_wf_light fills one shadow-task queue per vertex, which the NEE stages
+// walk deepest vertex first.  The arithmetic of every
 // stage is the same device code the fused kernel uses, so both pipelines give identical bits.
 #pragma once
 #include "pt_device.hpp"
@@ -35,8 +36,9 @@ struct WfState {
     int32_t* bod;    // [5][cap]  recorded bodies
     int32_t* nrec;   // [cap]
     int32_t* light;  // [cap]
-    int32_t* queue;  // [6][cap]
-    int32_t* qcount; // [8]
+    int32_t* need;   // [cap]     1 + deepest emitting vertex (scenes with a dead direct term), else 0
+    int32_t* queue;  // [11][cap] 0..5: paths with more than d-1 records; 6..10: shadow tasks of vertex 0..4
+    int32_t* qcount; // [16]
     size_t cap;
 };
 
@@ -181,6 +183,7 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         W.xy[W.cap + p] = y;
         store_rng(W, p, rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot));
         W.nrec[p] = 0;
+        W.need[p] = 0;
         store3(W.L, W.cap, p, 0, mk(0.0, 0.0, 0.0));
     }
     queue_push(W.queue, W.qcount, valid, (int)p);
@@ -237,7 +240,9 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int 
             Draws dr;
             dr.rng = load_rng(W, p);
             dr.count = 0;
-            V3 point = shade_hit(S.geom[hit], S.mat[hit], dr, o, d, W.t[p]);
+            const DMat& m = S.mat[hit];
+            V3 point = shade_hit(S.geom[hit], m, dr, o, d, W.t[p]);
+            if (m.emits) W.need[p] = depth + 1;
             store3(W.pts, W.cap, p, depth * 3, point);
             W.bod[(size_t)depth * W.cap + p] = hit;
             W.nrec[p] = depth + 1;
@@ -249,26 +254,40 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int 
     queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p);
 }
 
-// Light pick for every generated path (queue 0), next_event.cpp:390.
+constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks of vertex 0
+
+// Light pick for every generated path (queue 0), next_event.cpp:390, and the shadow-task queues.
+// In a scene whose direct term is dead (DScene::nee_emission_only) the colour recurrence starts at
+// zero and stays there until the deepest emitting vertex, so only vertices 0..need-1 get a shadow
+// ray; otherwise every recorded vertex does.
 __global__ void __launch_bounds__(kWfBlock) k_wf_light(DScene S, WfState W) {
     const int count = W.qcount[0];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if (i >= count) return;
-    const size_t p = (size_t)W.queue[i];
-    Draws dr;
-    dr.rng = load_rng(W, p);
-    dr.count = 0;
-    W.light[p] = pick_light(S, dr);
-    store_rng(W, p, dr.rng);
+    if ((int)(blockIdx.x * kWfBlock) >= count) return;
+    const bool active = i < count;
+    size_t p = 0;
+    int tasks = 0;
+    if (active) {
+        p = (size_t)W.queue[i];
+        Draws dr;
+        dr.rng = load_rng(W, p);
+        dr.count = 0;
+        W.light[p] = pick_light(S, dr);
+        store_rng(W, p, dr.rng);
+        tasks = S.nee_emission_only ? W.need[p] : W.nrec[p];
+    }
+    for (int g = 0; g < kMaxDepth; ++g)
+        queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, tasks > g, (int)p);
 }
 
-// NEE vertex gi for the paths of queue gi + 1 (those with more than gi records).
+// NEE vertex gi for the paths of its shadow-task queue.
 template <bool MEASURED, bool ELIDE>
 __global__ void __launch_bounds__(kWfBlock, MEASURED ? 2 : 4) k_wf_nee(DScene S, WfState W, int gi) {
-    const int count = W.qcount[gi + 1];
+    const int qi = kShadowQueue0 + gi;
+    const int count = W.qcount[qi];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
     if (i >= count) return;
-    const size_t p = (size_t)W.queue[(size_t)(gi + 1) * W.cap + i];
+    const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
     const int hit = W.hit[p];
     if (hit != W.bod[(size_t)gi * W.cap + p]) return;  // occluded: vertex skipped, next_event.cpp:428-430
     const int light = W.light[p];

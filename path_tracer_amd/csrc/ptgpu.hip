@@ -597,7 +597,7 @@ int upload_scene(pt_scene* s) {
     // The direct term of next-event estimation is dead for the whole scene when emission*colour of
     // every light is exactly zero and the flux it would be scaled by is finite for every material
     // (no measured tables, glass ior >= 1, finite colours); light indices must fit 7 bits.
-    bool dead = s->estimator == PT_EST_NEE && n <= kMaxBodiesFused && s->lights.size() >= 2;
+    bool dead = s->estimator == PT_EST_NEE && s->lights.size() >= 2;
     for (int i = 0; i < n && dead; ++i) {
         const pt_body& b = s->bodies[i];
         for (int k = 0; k < 3; ++k) dead = dead && std::isfinite(b.color[k]) && std::isfinite(b.emission[k]);
@@ -622,8 +622,8 @@ int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     const size_t cap = J * (size_t)s->wf_batch;
     if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
-    // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, queue 6 = 18
-    size_t bytes = cap * (27 * sizeof(double) + 18 * sizeof(int32_t)) + 64;
+    // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, need 1, queue 11 = 24
+    size_t bytes = cap * (27 * sizeof(double) + 24 * sizeof(int32_t)) + 64;
     int rc = s->d_wf.ensure(bytes);
     if (rc) return rc;
     ptw::WfState& W = s->wf;
@@ -640,8 +640,9 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.bod = W.hit + cap;
     W.nrec = W.bod + 5 * cap;
     W.light = W.nrec + cap;
-    W.queue = W.light + cap;
-    W.qcount = W.queue + 6 * cap;
+    W.need = W.light + cap;
+    W.queue = W.need + cap;
+    W.qcount = W.queue + 11 * cap;
     W.cap = cap;
     return PT_OK;
 }
@@ -653,7 +654,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const WfState W = s->wf;
     const Partition P = s->part;
     const int nblk = (int)((J * (size_t)B + kWfBlock - 1) / kWfBlock);
-    HIP_TRY(hipMemsetAsync(W.qcount, 0, 8 * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(W.qcount, 0, 16 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
     for (int depth = 0; depth < kMaxDepth; ++depth) {
         hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, 0);
@@ -662,7 +663,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     if (s->estimator == PT_EST_NEE) {
         hipLaunchKernelGGL(k_wf_light, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W);
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
-            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi + 1, gi);
+            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi);
             if (s->has_measured)
                 hipLaunchKernelGGL((k_wf_nee<true, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
             else
