@@ -140,6 +140,10 @@ PTD_INLINE double unif(Draws& d) {
 // double expression rounds to the same value, so no emulation is needed here.
 PTD_INLINE double unif_pm1(Draws& d) { return unif(d) * 2.0 - 1.0; }
 
+// Lane masks: a compare taken as a 64-bit wave mask (the SGPR pair v_cmp writes).
+typedef unsigned long long lanemask;
+#define PTD_MASK(cond) __builtin_amdgcn_ballot_w64(cond)
+
 // ---- scene records ---------------------------------------------------------------------
 struct DGeom {  // 64 bytes, what the nearest-hit scan reads
     double cx, cy, cz;
@@ -314,6 +318,16 @@ PTD_INLINE unsigned sphere_possible2(float ox, float oy, float oz, float dx, flo
 PTD_INLINE unsigned sphere_possible2(const RayF& rf, const DScreen2& sc) {
     return sphere_possible2(rf.ox, rf.oy, rf.oz, rf.dx, rf.dy, rf.dz, rf.e_disc, rf.e_b, sc);
 }
+// The same screen as wave masks: m0 / m1 = lanes that might hit body 0 / 1.
+PTD_INLINE void sphere_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
+                                       float e_b, const DScreen2& sc, lanemask& m0, lanemask& m1) {
+    f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
+    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
+    f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
+    f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
+    m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
+    m1 = PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b));
+}
 
 PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t);
 
@@ -359,8 +373,6 @@ PTD_INLINE void merge_hit(bool ok, double t, int i, int skip, int& hit, double& 
 // Lane masks: a compare is taken as a 64-bit wave mask (the SGPR pair v_cmp writes), combined with
 // scalar logic, and applied with v_cndmask.  Written out because the compiler otherwise
 // materialises selected booleans as 0/1 in vector registers.
-typedef unsigned long long lanemask;
-#define PTD_MASK(cond) __builtin_amdgcn_ballot_w64(cond)
 PTD_INLINE uint32_t sel32(lanemask m, uint32_t if_set, uint32_t if_clear) {
     uint32_t r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
@@ -445,9 +457,10 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
         const float e_disc = rf.e_disc, e_b = rf.e_b;
         for (int k = 0; 2 * k < n_spheres; ++k) {
             const DScreen2 sc = screen[k];
-            const unsigned m = sphere_possible2(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sc);
-            if (__builtin_amdgcn_ballot_w64((m & 1u) != 0) != 0) merge_sphere(spheres[2 * k], o, d, skip, hit, mint);
-            if (__builtin_amdgcn_ballot_w64((m & 2u) != 0) != 0) merge_sphere(spheres[2 * k + 1], o, d, skip, hit, mint);
+            lanemask m0, m1;
+            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
+            if (m0 != 0) merge_sphere(spheres[2 * k], o, d, skip, hit, mint);
+            if (m1 != 0) merge_sphere(spheres[2 * k + 1], o, d, skip, hit, mint);
         }
     }
     tmin = mint;

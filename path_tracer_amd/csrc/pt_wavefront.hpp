@@ -94,6 +94,8 @@ struct TileLds {
 PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2* __restrict__ screen, int n, V3 o, V3 d,
                                  int skip, bool active, float c1max, float r2max, TileLds* tile, double& tmin) {
     const RayF rf = make_rayf(o, d, c1max, r2max);
+    const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
+    const float e_disc = rf.e_disc, e_b = rf.e_b;
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     for (int base = 0; base < n; base += kTileBodies) {
@@ -118,15 +120,16 @@ PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2*
             for (int q = 0; q < steps; ++q) {
                 const DScreen2 sa = tile->scr[2 * q];  // same address in every lane: LDS broadcast
                 const DScreen2 sb = tile->scr[2 * q + 1];
-                const unsigned possible = sphere_possible2(rf, sa) | (sphere_possible2(rf, sb) << 2);
-                // OR over the wave: which of the four bodies needs the exact test by some lane
-                unsigned long long any = __builtin_amdgcn_ballot_w64(possible != 0);
-                if (any == 0) continue;
-                unsigned need = 0;
-                for (int h = 0; h < 4; ++h)
-                    if (__builtin_amdgcn_ballot_w64((possible >> h) & 1u) != 0) need |= 1u << h;
+                // per body, the lanes that need the exact test (wave masks on the scalar unit)
+                lanemask need[4];
+                sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
+                sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
+                if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
+                const unsigned bodies = (need[0] != 0 ? 1u : 0u) | (need[1] != 0 ? 2u : 0u) | (need[2] != 0 ? 4u : 0u) |
+                                        (need[3] != 0 ? 8u : 0u);
+#pragma unroll 1
                 for (int h = 0; h < 4; ++h) {
-                    if (!((need >> h) & 1u)) continue;
+                    if (!((bodies >> h) & 1u)) continue;
                     const int i = 4 * q + h;
                     if (i >= cnt) break;
                     DGeom g = tile->geom[i];
