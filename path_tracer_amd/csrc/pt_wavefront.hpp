@@ -23,7 +23,7 @@ namespace ptw {
 using namespace ptd;
 
 constexpr int kWfBlock = 256;
-constexpr int kTileBodies = 512;  // 512 x (64 + 16) B = 40 KiB of LDS per block: 4 blocks per CU
+constexpr int kTileBodies = 1024;  // 1024 x 16 B of screening records = 16 KiB of LDS per block
 
 struct WfState {
     double* ray;     // [6][cap]  origin xyz, direction xyz
@@ -78,17 +78,15 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 }
 
 // Nearest-hit scan with the body list staged through LDS in tiles of kTileBodies bodies.  A tile
-// holds two images: 32-byte screening records (float sphere data of two consecutive bodies) and the
-// full 64-byte records.  Per pair of bodies a wave reads the screening record (broadcast LDS read)
-// and runs the packed float screen; only when some lane might hit does it read a full record and
-// evaluate in FP64.  In a
-// scene of many small spheres almost every (wave, body) pair ends at the screen, which keeps the
-// LDS pipe (one 64-byte record per body per wave would saturate it) and the FP64 units free.
+// holds the 32-byte screening records (float sphere data of two consecutive bodies).  Per four
+// bodies a wave reads two screening records (broadcast LDS reads) and runs the packed float screen;
+// only when some lane might hit does it fetch the full 64-byte record (scalar load at a
+// wave-uniform address) and evaluate in FP64.  In a scene of many small spheres almost every
+// (wave, body) pair ends at the screen, which keeps the LDS pipe and the FP64 units free.
 // Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
-// Same acceptance rule and body order as ptd::nearest_hit.
+// Same acceptance rule and body order as the reference scan.
 struct TileLds {
     DScreen2 scr[kTileBodies / 2];
-    DGeom geom[kTileBodies];
 };
 
 PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2* __restrict__ screen, int n, V3 o, V3 d,
@@ -102,9 +100,6 @@ PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2*
         const int cnt = min(kTileBodies, n - base);
         __syncthreads();  // the previous tile has been consumed by every wave
         {
-            const uint4* src = reinterpret_cast<const uint4*>(geom + base);
-            uint4* dst = reinterpret_cast<uint4*>(tile->geom);
-            for (int k = threadIdx.x; k < cnt * 4; k += blockDim.x) dst[k] = src[k];  // 16 B per lane, coalesced
             const uint4* ssrc = reinterpret_cast<const uint4*>(screen + base / 2);
             uint4* sdst = reinterpret_cast<uint4*>(tile->scr);
             const int have = ((cnt + 1) / 2) * 2;    // uint4 units present in global memory
@@ -132,8 +127,8 @@ PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2*
                     if (!((bodies >> h) & 1u)) continue;
                     const int i = 4 * q + h;
                     if (i >= cnt) break;
-                    DGeom g = tile->geom[i];
-                    const int shape = __builtin_amdgcn_readfirstlane(g.shape);
+                    const DGeom g = geom[base + i];  // wave-uniform address: scalar load, rare
+                    const int shape = g.shape;
                     double t;
                     bool ok;
                     switch (shape) {
