@@ -12,7 +12,11 @@
 //
 // Extra options, after the four positionals: --seed N (default: time, like srand(time(NULL))),
 // --gpu ID, --out PATH, --literal-height (next_event only: height = argv[1] as
-// next_event.cpp:596 literally does), --quiet.
+// next_event.cpp:596 literally does), --quiet, and --progressive: the output loop the reference
+// keeps commented out (main.cpp:614-640): rounds of min(10, max(remaining / T, 1)) iterations per
+// worker, the image saved after every round with the iterations done so far as sample count
+// (main: output_<done>.ppm, next_event: output.ppm rewritten), "Iterations between output: n" on
+// stdout.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +38,7 @@ int main(int argc, const char* argv[]) {
     int thread_count = (int)strtol(argv[4], NULL, 10);
     uint64_t seed = (uint64_t)time(NULL);
     int gpu = 0;
-    bool quiet = false;
+    bool quiet = false, progressive = false;
     std::string out;
     for (int i = 5; i < argc; ++i) {
         std::string a = argv[i];
@@ -42,6 +46,7 @@ int main(int argc, const char* argv[]) {
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else if (a == "--quiet") quiet = true;
+        else if (a == "--progressive") progressive = true;
 #ifdef PT_PROG_NEE
         else if (a == "--literal-height") height = width;
 #endif
@@ -51,6 +56,8 @@ int main(int argc, const char* argv[]) {
         }
     }
     if (thread_count < 1) thread_count = 1;
+    const bool user_out = !out.empty();
+    (void)user_out;
 #ifdef PT_PROG_NEE
     const char* preset = "nee15";
     int per_worker = iterations / thread_count;                          // next_event.cpp:703
@@ -79,22 +86,58 @@ int main(int argc, const char* argv[]) {
     size_t n = (size_t)width * height * 3;
     std::vector<double> buffer(n, 0.0), priv;
     auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < thread_count; ++k) {
-        double* dst = buffer.data();
-        if (thread_count > 1) {
-            priv.assign(n, 0.0);
-            dst = priv.data();
+    double frames = 0.0;
+    if (progressive) {
+        // main.cpp:614-640: every worker renders `iteration_step` frames into a private buffer that
+        // is then added to the shared one; the image is saved after each round.
+        int iterations_remaining = iterations, next_iteration = 0;
+        while (iterations_remaining > 0) {
+            int iteration_step = (int)((double)iterations_remaining / (double)thread_count);
+            if (iteration_step < 1) iteration_step = 1;
+            if (iteration_step > 10) iteration_step = 10;
+            printf("Iterations between output: %d\n", iteration_step);
+            for (int k = 0; k < thread_count; ++k) {
+                priv.assign(n, 0.0);
+                if (pt_render(scene, next_iteration, iteration_step, priv.data()) != PT_OK) {
+                    fprintf(stderr, "ptgpu: %s\n", pt_last_error());
+                    return 1;
+                }
+                for (size_t i = 0; i < n; ++i) buffer[i] += priv[i];
+                next_iteration += iteration_step;
+                iterations_remaining -= iteration_step;
+                frames += iteration_step;
+            }
+            const int done = iterations - iterations_remaining;
+#ifdef PT_PROG_NEE
+            std::string name = out;
+#else
+            std::string name = user_out ? out + "." + std::to_string(done) : "output_" + std::to_string(done) + ".ppm";
+            printf("saving to file \"%s\"\n", name.c_str());
+#endif
+            if (pt_save_ppm(buffer.data(), done, width, height, name.c_str()) != PT_OK) {
+                fprintf(stderr, "cannot write %s\n", name.c_str());
+                return 1;
+            }
         }
-        if (pt_render(scene, k * per_worker, per_worker, dst) != PT_OK) {
-            fprintf(stderr, "ptgpu: %s\n", pt_last_error());
-            return 1;
+    } else {
+        for (int k = 0; k < thread_count; ++k) {
+            double* dst = buffer.data();
+            if (thread_count > 1) {
+                priv.assign(n, 0.0);
+                dst = priv.data();
+            }
+            if (pt_render(scene, k * per_worker, per_worker, dst) != PT_OK) {
+                fprintf(stderr, "ptgpu: %s\n", pt_last_error());
+                return 1;
+            }
+            if (thread_count > 1)
+                for (size_t i = 0; i < n; ++i) buffer[i] += priv[i];
         }
-        if (thread_count > 1)
-            for (size_t i = 0; i < n; ++i) buffer[i] += priv[i];
+        frames = (double)per_worker * thread_count;
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!quiet) {
-        double paths = (double)width * height * (double)per_worker * thread_count;
+        double paths = (double)width * height * frames;
         fprintf(stderr, "ptgpu: %.0f paths in %.3f s = %.3e paths/s (seed %llu)\n", paths, secs, paths / secs,
                 (unsigned long long)seed);
     }

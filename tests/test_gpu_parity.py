@@ -402,3 +402,31 @@ def test_frames_with_extra_planes(port, name, W, H, n_it):
     r.set_partition(0, 1)
     assert np.count_nonzero(part) > 0 and same_bits(part[part != 0], want[part != 0])
     r.close()
+
+
+def test_progressive_output_loop(port, tmp_path):
+    """--progressive: the save-every-round loop the reference keeps commented out (main.cpp:614-640)."""
+    import subprocess
+
+    from conftest import ROOT
+
+    W, H, iters, threads = 24, 16, 7, 2
+    out = str(tmp_path / "prog.ppm")
+    exe = os.path.join(ROOT, "path_tracer_amd", "bin", "main")
+    res = subprocess.run([exe, str(W), str(H), str(iters), str(threads), "--seed", "5", "--out", out, "--quiet",
+                          "--progressive"], check=True, timeout=120, capture_output=True, text=True)
+    assert res.stdout.count("Iterations between output: 3") == 1 and res.stdout.count("Iterations between output: 1") == 1
+    r = pt.Renderer(pt.preset("main32", W, H, seed=5))
+    s = oracle_scene(port, r, W, H, 5)
+    total = np.zeros((H, W, 3))
+    first = 0
+    for step, done in ((3, 6), (1, 8)):  # rounds of min(10, max(remaining / T, 1)) frames per worker
+        for _ in range(threads):
+            priv, _ = port.render(s, MODE_PIXEL, first, step)
+            total = total + priv
+            first += step
+        with open(f"{out}.{done}", "rb") as f:
+            assert f.read() == port.save_ppm(total, done, W, H)
+    with open(out, "rb") as f:
+        assert f.read() == port.save_ppm(total, iters, W, H)  # the final save divides by the requested total
+    r.close()
