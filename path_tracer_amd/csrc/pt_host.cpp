@@ -147,6 +147,27 @@ void scene_main32(Builder& B) {
     emitter(B.sphere(0.63333, -2.5, 2.1, 0.1), e[0], e[1], e[2]);   // front2     :586
 }
 
+// bipath2.cpp:605-725, array order :722-724: the common bodies with next_event's small spheres,
+// main's top-left divider position, a dimmer top light that still counts as a light
+// (emission.x == 1.0 >= 1.0, next_event.cpp:364) and ten sphere lights: eleven lights in all,
+// which exercises the light pick of next_event.cpp:390 beyond two lights.
+void scene_bipath23(Builder& B) {
+    common_bodies(B, true);
+    if (B.overflow) return;
+    Builder::set3(B.out[10].emission, 1.0, 0.87, 0.69);  // top light   bipath2.cpp:659
+    Builder::set3(B.out[12].center, -1.8, 4.4, 2.4);     // top-left divider :669
+    const double e[3] = {2.0, 1.87, 1.69};
+    emitter(B.sphere(1.9, 3.0, 2.1, 0.1), e[0], e[1], e[2]);        // right  :673
+    emitter(B.sphere(-1.9, 3.0, 2.1, 0.1), e[0], e[1], e[2]);       // left   :677
+    emitter(B.sphere(-0.63333, 4.5, 2.1, 0.1), e[0], e[1], e[2]);   // back   :705
+    emitter(B.sphere(0.63333, 4.5, 2.1, 0.1), e[0], e[1], e[2]);    // back2  :709
+    const double ys[3] = {3.75, 2.25, 1.5};                         // right2..4 / left2..4 :681-703
+    for (double y : ys) {
+        emitter(B.sphere(1.9, y, 2.1, 0.1), e[0], e[1], e[2]);
+        emitter(B.sphere(-1.9, y, 2.1, 0.1), e[0], e[1], e[2]);
+    }
+}
+
 // 64-bit LCG used only to lay out the synthetic 10k-primitive scene.
 struct Lcg {
     uint64_t s;
@@ -235,6 +256,9 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
             Builder::set3(bodies[10].color, 1.0, 1.0, 1.0);
             Builder::set3(bodies[14].color, 1.0, 1.0, 1.0);
         }
+    } else if (s == "bipath23") {  // next_event's estimator on bipath2.cpp's 23-body scene
+        desc->estimator = PT_EST_NEE;
+        scene_bipath23(B);
     } else if (s == "synthetic10k") {
         desc->estimator = PT_EST_NEE;
         scene_synthetic(B, 9985);

@@ -11,7 +11,7 @@ from _oracle import EST_NEE, EST_PT, MODE_PIXEL
 from conftest import GOLDEN, same_bits
 
 pytestmark = pytest.mark.gpu
-EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE}
+EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE, "bipath23": EST_NEE}
 
 
 def oracle_scene(port, renderer, W, H, seed, flags=0, tables=None):
@@ -86,7 +86,7 @@ def test_frame_layout(port, W, H, seed):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["nee15", "main32", "pt15", "nee15_lit"])
+@pytest.mark.parametrize("name", ["nee15", "main32", "pt15", "nee15_lit", "bipath23"])
 def test_paths_match_oracle(port, name):
     rng = np.random.default_rng(11)
     n = 20000
@@ -99,7 +99,7 @@ def test_paths_match_oracle(port, name):
     assert np.array_equal(g["nrec"], o["nrec"])
     assert np.array_equal(g["bodies"], o["bodies"])
     assert np.array_equal(g["draws"], o["draws"])
-    if name.startswith("nee15"):
+    if EST[name] == EST_NEE:
         assert np.array_equal(g["visible"], o["visible"])
     # offset points: the oracle mirrors the reference's x87 islands, the GPU is plain FP64
     np.testing.assert_allclose(g["points"], o["points"], rtol=1e-12, atol=1e-13)
@@ -120,7 +120,7 @@ def test_golden_frames(port):
 
 
 @pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40),
-                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4)])
+                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4), ("bipath23", 72, 40, 4)])
 def test_frames_match_oracle(port, name, W, H, n_it):
     r = pt.Renderer(pt.preset(name, W, H, seed=2025))
     s = oracle_scene(port, r, W, H, 2025)
@@ -250,7 +250,8 @@ def open_scene(name, W, H, seed, drop=(7, 8, 9, 10, 11, 12, 13)):
     return d
 
 
-@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 70, 40, 4), ("main32", 48, 48, 3), ("nee15_lit", 64, 24, 3)])
+@pytest.mark.parametrize("name,W,H,n_it", [("nee15", 70, 40, 4), ("main32", 48, 48, 3), ("nee15_lit", 64, 24, 3),
+                                           ("bipath23", 40, 30, 3)])
 def test_wavefront_equals_fused_and_oracle(port, name, W, H, n_it):
     r = pt.Renderer(pt.preset(name, W, H, seed=31))
     want, _ = port.render(oracle_scene(port, r, W, H, 31), MODE_PIXEL, 2, n_it)
