@@ -236,9 +236,73 @@ long long render(int W, int H, int first_it, int n_it, int mode, uint64_t seed, 
     return draws;
 }
 
+// Frames of the reference's Renderer::iterate() on a caller-supplied body list: the bodies are
+// built with the reference's own constructors from their constructor arguments (Plane normalises
+// its normal, main.cpp:176-179), replace the scene's object array, and the reference Renderer is
+// constructed from that scene (which rebuilds the light list, next_event.cpp:362-367).
+template <class T>
+long long render_custom(const ptor_body* bodies, int n, int W, int H, int first_it, int n_it, int mode, uint64_t seed,
+                        double* buffer_out) {
+    long long draws = -1;
+    with_scene<T>([&](typename T::Scene* s) {
+        typedef typename T::V3 V3;
+        std::vector<typename T::Shape*> shapes;
+        std::vector<typename T::Material*> mats;
+        std::vector<typename T::Body*> objs;
+        for (int i = 0; i < n; i++) {
+            const ptor_body& b = bodies[i];
+            typename T::Shape* sh;
+            if (b.shape == PTOR_PLANE)
+                sh = new typename T::Plane(V3(b.center[0], b.center[1], b.center[2]), V3(b.normal[0], b.normal[1], b.normal[2]));
+            else
+                sh = new typename T::Sphere(V3(b.center[0], b.center[1], b.center[2]), b.radius);
+            V3 col(b.color[0], b.color[1], b.color[2]), em(b.emission[0], b.emission[1], b.emission[2]);
+            typename T::Material* m;
+            if (b.material == PTOR_GLASS) {
+                m = new typename T::Glass(col, b.ior, b.reflection);
+                m->emission = em;
+            } else if (b.material == PTOR_CHROME) {
+                m = new typename T::Chrome(col);
+                m->emission = em;
+            } else {
+                m = new typename T::Material(col, em);
+            }
+            shapes.push_back(sh);
+            mats.push_back(m);
+            objs.push_back(new typename T::Body(sh, m));
+        }
+        typename T::Scene sc = *s;
+        sc.width = W;
+        sc.height = H;
+        sc.body_count = n;
+        sc.objects = objs.data();
+        {
+            typename T::Renderer r(sc);
+            set_mode<T>(mode, seed, 0, 0);
+            for (int it = first_it; it < first_it + n_it; it++) {
+                ptor_rt_begin_iteration((uint32_t)it);
+                r.iterate();
+            }
+            draws = ptor_rt_draws();
+            for (int i = 0; i < W * H; i++) put3(buffer_out + 3 * (size_t)i, r.buffer[i]);
+        }
+        for (auto* o : objs) delete o;
+        for (auto* m : mats) delete m;
+        for (auto* sh : shapes) delete sh;
+    });
+    return draws;
+}
+
 }  // namespace
 
 extern "C" {
+
+// ptor_render on a caller-supplied body list (constructor arguments, see render_custom).
+long long ptor_render_custom(int prog, const ptor_body* bodies, int n, int W, int H, int first_it, int n_it, int mode,
+                             uint64_t seed, double* buffer_out) {
+    return prog == 0 ? render_custom<PT>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out)
+                     : render_custom<NEE>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out);
+}
 
 int ptor_set_scratch(const char* dir) {
     g_scratch = dir;

@@ -149,8 +149,9 @@ void scene_main32(Builder& B) {
 
 // bipath2.cpp:605-725, array order :722-724: the common bodies with next_event's small spheres,
 // main's top-left divider position, a dimmer top light that still counts as a light
-// (emission.x == 1.0 >= 1.0, next_event.cpp:364) and ten sphere lights: eleven lights in all,
-// which exercises the light pick of next_event.cpp:390 beyond two lights.
+// (emission.x == 1.0 >= 1.0, next_event.cpp:364) and nine sphere lights — the array lists a tenth,
+// left4, but body_count is 23 (:721), so it is never seen: ten lights in all, which exercises the
+// light pick of next_event.cpp:390 beyond two lights.
 void scene_bipath23(Builder& B) {
     common_bodies(B, true);
     if (B.overflow) return;
@@ -162,9 +163,9 @@ void scene_bipath23(Builder& B) {
     emitter(B.sphere(-0.63333, 4.5, 2.1, 0.1), e[0], e[1], e[2]);   // back   :705
     emitter(B.sphere(0.63333, 4.5, 2.1, 0.1), e[0], e[1], e[2]);    // back2  :709
     const double ys[3] = {3.75, 2.25, 1.5};                         // right2..4 / left2..4 :681-703
-    for (double y : ys) {
-        emitter(B.sphere(1.9, y, 2.1, 0.1), e[0], e[1], e[2]);
-        emitter(B.sphere(-1.9, y, 2.1, 0.1), e[0], e[1], e[2]);
+    for (int k = 0; k < 3; ++k) {
+        emitter(B.sphere(1.9, ys[k], 2.1, 0.1), e[0], e[1], e[2]);
+        if (k < 2) emitter(B.sphere(-1.9, ys[k], 2.1, 0.1), e[0], e[1], e[2]);
     }
 }
 

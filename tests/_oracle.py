@@ -291,6 +291,14 @@ class Ref:
         )
         return buf, draws
 
+    def render_custom(self, prog, bodies, n, W, H, first_it, n_it, mode, seed=1):
+        """Frames of the reference's iterate() on a caller-supplied body list (constructor arguments)."""
+        buf = np.zeros((H, W, 3))
+        self.lib.ptor_render_custom.restype = C.c_longlong
+        draws = self.lib.ptor_render_custom(prog, bodies, n, W, H, first_it, n_it, mode, C.c_uint64(seed), _p(buf))
+        assert draws >= 0
+        return buf, draws
+
     def trace_pt(self, rays6, seed, iteration):
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64)
         rgb = np.zeros((rays6.shape[0], 3))
@@ -315,3 +323,27 @@ class Ref:
         chk = C.c_double()
         secs = self.lib.ptor_time_iterate(prog, W, H, iters_per_thread, threads, C.c_uint64(seed), C.byref(chk))
         return secs, chk.value
+
+
+def bodies_to_bytes(bodies, n):
+    """Body array -> uint8 numpy array (the 136-byte records, exact)."""
+    return np.frombuffer(bytes(bodies)[: n * C.sizeof(Body)], dtype=np.uint8).copy()
+
+
+def bodies_from_bytes(raw):
+    n = raw.size // C.sizeof(Body)
+    arr = (Body * n).from_buffer_copy(raw.tobytes())
+    return arr, n
+
+
+def constructed(port, bodies, n):
+    """What the reference's constructors store for these constructor arguments: Plane keeps
+    normalize(normal) (main.cpp:176-179), everything else is kept as given."""
+    out = (Body * n)()
+    for i in range(n):
+        out[i] = Body.from_buffer_copy(bodies[i])
+        if out[i].shape == PLANE:
+            nn = port.plane_normal(np.array(list(bodies[i].normal)))
+            for k in range(3):
+                out[i].normal[k] = nn[k]
+    return out

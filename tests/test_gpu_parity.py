@@ -9,6 +9,7 @@ import pytest
 import path_tracer_amd as pt
 from _oracle import EST_NEE, EST_PT, MODE_PIXEL
 from conftest import GOLDEN, same_bits
+from _scenes import open_scene, scene_with_extra_planes
 
 pytestmark = pytest.mark.gpu
 EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE, "bipath23": EST_NEE}
@@ -237,19 +238,6 @@ def test_errors_are_reported_not_fatal():
     r.close()
 
 
-def open_scene(name, W, H, seed, drop=(7, 8, 9, 10, 11, 12, 13)):
-    """A reference scene with some walls removed, so that paths leave the scene and terminate."""
-    d = pt.preset(name, W, H, seed=seed)
-    keep = [i for i in range(d.body_count) if i not in drop]
-    bodies = (pt.Body * len(keep))()
-    for k, i in enumerate(keep):
-        bodies[k] = d.bodies[i]
-    d.bodies = bodies
-    d.body_count = len(keep)
-    d._keep = bodies
-    return d
-
-
 @pytest.mark.parametrize("name,W,H,n_it", [("nee15", 70, 40, 4), ("main32", 48, 48, 3), ("nee15_lit", 64, 24, 3),
                                            ("bipath23", 40, 30, 3)])
 def test_wavefront_equals_fused_and_oracle(port, name, W, H, n_it):
@@ -326,31 +314,6 @@ def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
         with open(out, "rb") as f:
             assert f.read() == port.save_ppm(total, iters, W, H)
         r.close()
-
-
-def scene_with_extra_planes(name, W, H, seed):
-    """The reference scene plus axis-aligned planes that stress the slab form of the scan: a plane
-    coincident with the left wall (a tie between bodies), a third x plane inside the box, a second
-    emitting z plane above the top light and a duplicate of the back wall with the opposite normal."""
-    d = pt.preset(name, W, H, seed=seed)
-    n = d.body_count
-    extra = [(8, None), (8, (0.5, 0.0, 0.0)), (10, (0.0, 0.0, 3.0)), (7, "flip")]  # 7 back, 8 left, 10 top light
-    bodies = (pt.Body * (n + len(extra)))()
-    for i in range(n):
-        bodies[i] = d.bodies[i]
-    for k, (src, change) in enumerate(extra):
-        b = pt.Body.from_buffer_copy(d.bodies[src])
-        if change == "flip":
-            for c in range(3):
-                b.normal[c] = -b.normal[c]
-        elif change is not None:
-            for c in range(3):
-                b.center[c] = change[c]
-        bodies[n + k] = b
-    d.bodies = bodies
-    d.body_count = n + len(extra)
-    d._keep = bodies
-    return d
 
 
 def edge_rays(rng, n):
@@ -430,4 +393,32 @@ def test_progressive_output_loop(port, tmp_path):
             assert f.read() == port.save_ppm(total, done, W, H)
     with open(out, "rb") as f:
         assert f.read() == port.save_ppm(total, iters, W, H)  # the final save divides by the requested total
+    r.close()
+
+
+def _custom_cases():
+    with open(os.path.join(GOLDEN, "frames_custom.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _custom_cases(), ids=lambda c: c["key"])
+def test_custom_scene_golden_frames(case):
+    """Scenes the reference does not hard-code, rendered by the reference's own classes from the same
+    constructor arguments (ten lights, coincident/extra planes, open walls, 1000 bodies -> wavefront)."""
+    import ctypes as C
+
+    z = np.load(os.path.join(GOLDEN, "frames_custom.npz"))
+    raw = z[case["key"] + "_bodies"]
+    n = raw.size // C.sizeof(pt.Body)
+    assert n == case["bodies"]
+    d = pt.preset("nee15" if case["prog"] == 1 else "main32", case["W"], case["H"], seed=case["seed"])
+    bodies = (pt.Body * n).from_buffer_copy(raw.tobytes())
+    d.bodies = bodies
+    d.body_count = n
+    d._keep = bodies
+    r = pt.Renderer(d)
+    assert same_bits(r.render(case["first"], case["n_it"]), z[case["key"] + "_frame"])
+    if n <= 127:
+        r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+        assert same_bits(r.render(case["first"], case["n_it"]), z[case["key"] + "_frame"])
     r.close()

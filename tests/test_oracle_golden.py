@@ -106,3 +106,25 @@ def test_frame_layout_short_rows(port, golden_scene):
         assert set(rl[:rows].tolist()) <= {1023, 1024}
         short += int((rl[:rows] == 1023).sum())
     assert 0 < short < 20  # about 1 % of rows at W = 1024
+
+
+def custom_cases():
+    with open(os.path.join(GOLDEN, "frames_custom.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", custom_cases(), ids=lambda c: c["key"])
+def test_custom_scene_frames_match_reference(port, golden_scene, case):
+    """Scenes the reference does not hard-code (ten lights, coincident and extra planes, open walls,
+    1000 bodies): the restatement against frames the reference's own classes rendered from the same
+    constructor arguments (tests/golden/make_golden_custom.py)."""
+    z = np.load(os.path.join(GOLDEN, "frames_custom.npz"))
+    args, n = _oracle.bodies_from_bytes(z[case["key"] + "_bodies"])
+    assert n == case["bodies"]
+    stored = _oracle.constructed(port, args, n)
+    _, _, cam = golden_scene("nee15")  # every program of the reference uses the same camera
+    est = EST_NEE if case["prog"] == 1 else EST_PT
+    s = port.scene(stored, n, cam, case["W"], case["H"], est, seed=case["seed"])
+    got, draws = port.render(s, MODE_PIXEL, case["first"], case["n_it"])
+    assert same_bits(got, z[case["key"] + "_frame"])
+    assert draws == case["draws"]
