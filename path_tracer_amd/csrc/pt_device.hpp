@@ -732,6 +732,17 @@ PTD_INLINE V3 light_term(const DScene& S, int light) {
     return mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
 }
 
+// The measured-material term of a lit vertex: both directions to spherical angles, then the table
+// lookup.  Kept out of line: its trigonometric expansions need about 200 vector registers, which
+// inlined would set the register budget (and the occupancy) of the whole estimator kernel; as a
+// call, only the waves that reach a measured vertex pay for it.
+__device__ __attribute__((noinline)) V3 measured_term(const double* __restrict__ table, V3 bd, V3 nprime) {
+    double ti, pi, to, po;
+    vector_to_spherical(bd, ti, pi);
+    vector_to_spherical(nprime, to, po);
+    return brdf_lookup(table, ti, pi, to, po, nullptr);
+}
+
 // One lit vertex of the NEE loop (next_event.cpp:442-463): L = ((L + (Le*Lc)*flux) * c) + e.
 // `bd` is the shadow-ray direction, `next_point` the previous vertex (or the camera-plane point
 // for vertex 0, next_event.cpp:443-447).
@@ -750,10 +761,7 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
     if (MEASURED && m.material == kMeasured) {
         // Defined by this build: the table RGB replaces the scalar flux (the reference's own
         // lookups, raytrace3.cpp:646-676, are never executed).
-        double ti, pi, to, po;
-        vector_to_spherical(bd, ti, pi);
-        vector_to_spherical(nprime, to, po);
-        V3 f = brdf_lookup(S.brdf[m.brdf_id], ti, pi, to, po, nullptr);
+        V3 f = measured_term(S.brdf[m.brdf_id], bd, nprime);
         scale = mul(lterm, f);
     } else {
         V3 light_brdf = bounce(m, dr, bd, nprime);

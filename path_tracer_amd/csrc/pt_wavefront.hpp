@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_light(DScene S, WfState W) {
 
 // NEE vertex gi for the paths of its shadow-task queue.
 template <bool MEASURED, bool ELIDE>
-__global__ void __launch_bounds__(kWfBlock, MEASURED ? 2 : 4) k_wf_nee(DScene S, WfState W, int gi) {
+__global__ void __launch_bounds__(kWfBlock, 4) k_wf_nee(DScene S, WfState W, int gi) {
     const int qi = kShadowQueue0 + gi;
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;

@@ -135,13 +135,13 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 
 // ---- k_trace -----------------------------------------------------------------------------
 // __launch_bounds__(256, 5): five 256-thread blocks per CU (5 waves per SIMD).  Their LDS records
-// (5 x 32000 B) just fit the 160 KiB of a CU and the register file allows 96 VGPRs per lane; the
-// estimator is latency-bound on FP64 dependency chains, and the fifth wave buys ~8 %.  The variant
-// with the measured-BRDF lookup (sin/cos/acos/atan2 expansions) needs ~240 registers and runs at 2.
+// (5 x 32 KB) just fit the 160 KiB of a CU and the register file allows 96 VGPRs per lane; the
+// estimator is bound by VALU issue, and the fifth wave buys ~8 %.  The variant with the
+// measured-BRDF lookup calls it out of line (104 registers) and runs at 4.
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
 // shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, MEASURED ? 2 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, MEASURED ? 4 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
