@@ -147,14 +147,14 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, launches = 0.0, 0.0
+    kernel_ms, launches, traced = 0.0, 0.0, 0.0
     for _ in range(args.steps):
         step()
-        if world == 1:
-            torch.cuda.synchronize()
-            st = r.stats()  # HIP events recorded on the render stream around every estimator launch
-            kernel_ms += st["kernel_ms"]
-            launches += st["launches"]
+        torch.cuda.synchronize()
+        st = r.stats()  # HIP events recorded on the render stream around every estimator launch (this rank)
+        kernel_ms += st["kernel_ms"]
+        launches += st["launches"]
+        traced += st["paths"]
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -188,8 +188,8 @@ def main():
                 "mean_radiance": checksum,
             },
         }
-        if world == 1 and launches > 0:
-            paths_per_launch = float(W) * H * IT * args.steps / launches
+        if launches > 0:
+            paths_per_launch = traced / launches  # rank 0's own launches: a per-GPU figure when N > 1
             avg_ms = kernel_ms / launches
             achieved = paths_per_launch * flop_per_path / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {
@@ -210,7 +210,9 @@ def main():
                 "launches": launches,
                 "flop_per_path": flop_per_path,
             }
-            if not args.no_cpu:
+            if world > 1:
+                out["roofline"]["note"] = "rank 0's kernel launches; per-GPU rate"
+            if world == 1 and not args.no_cpu:
                 cb = cpu_baseline(W, H, args.cpu_seconds)
                 out["cpu_baseline"] = cb
                 out["config"]["gpu_over_cpu"] = out["value"] / cb["value"]
