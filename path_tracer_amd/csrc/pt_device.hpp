@@ -135,10 +135,9 @@ PTD_INLINE double unif(Draws& d) {
     d.count++;
     return k_to_unit(rng_next(d.rng));
 }
-// unifRand()*2.0L-1.0L narrowed to double (main.cpp:108).  For u >= 2^-13 the extended-precision
-// difference is exact, and for the 2^18 smaller draws an exhaustive check shows that the plain
-// double expression rounds to the same value, so no emulation is needed here.
-PTD_INLINE double unif_pm1(Draws& d) { return unif(d) * 2.0 - 1.0; }
+// unifRand()*2.0L-1.0L narrowed to double (main.cpp:108) is written u * 2.0 - 1.0: for
+// u >= 2^-13 the extended-precision difference is exact, and for the 2^18 smaller draws an
+// exhaustive check shows that the plain double expression rounds to the same value.
 
 // Lane masks: a compare taken as a 64-bit wave mask (the SGPR pair v_cmp writes).
 typedef unsigned long long lanemask;
@@ -160,7 +159,7 @@ struct DGeom {  // 64 bytes, what the nearest-hit scan reads
     int32_t pad[3];
 };
 
-// Per-ray data of the single-precision sphere screen (see scan_sphere).
+// Per-ray data of the single-precision sphere screen (see make_rayf).
 struct RayF {
     float ox, oy, oz, dx, dy, dz;
     float e_disc;  // |float disc - exact disc| is below this for every sphere of the scene
@@ -294,31 +293,8 @@ PTD_INLINE RayF make_rayf(V3 o, V3 d, float c1max, float r2max) {
     return r;
 }
 
-// True when this lane certainly cannot hit the sphere (cx, cy, cz, r2 in float).
-PTD_INLINE bool sphere_impossible(const RayF& rf, float cx, float cy, float cz, float r2) {
-    float Dx = rf.ox - cx, Dy = rf.oy - cy, Dz = rf.oz - cz;
-    float bf = Dx * rf.dx + Dy * rf.dy + Dz * rf.dz;
-    float cf = (Dx * Dx + Dy * Dy + Dz * Dz) - r2;
-    float discf = bf * bf - cf;
-    return (discf < -rf.e_disc) || (bf > rf.e_b);
-}
-
-// The same screen for two bodies at once (packed FP32).  Returns, per lane, bit 0 / bit 1 set when
-// body 0 / 1 MIGHT be hit (NaN compares as "might").
-PTD_INLINE unsigned sphere_possible2(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc, float e_b,
-                                     const DScreen2& sc) {
-    f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
-    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
-    f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
-    f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
-    unsigned p0 = (!(discf.x < -e_disc) && !(bf.x > e_b)) ? 1u : 0u;
-    unsigned p1 = (!(discf.y < -e_disc) && !(bf.y > e_b)) ? 2u : 0u;
-    return p0 | p1;
-}
-PTD_INLINE unsigned sphere_possible2(const RayF& rf, const DScreen2& sc) {
-    return sphere_possible2(rf.ox, rf.oy, rf.oz, rf.dx, rf.dy, rf.dz, rf.e_disc, rf.e_b, sc);
-}
-// The same screen as wave masks: m0 / m1 = lanes that might hit body 0 / 1.
+// The screen for two bodies at once (packed FP32), as wave masks: m0 / m1 = lanes that might hit
+// body 0 / 1 (NaN compares as "might").
 PTD_INLINE void sphere_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
                                        float e_b, const DScreen2& sc, lanemask& m0, lanemask& m1) {
     f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
@@ -327,14 +303,6 @@ PTD_INLINE void sphere_possible2_masks(float ox, float oy, float oz, float dx, f
     f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
     m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
     m1 = PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b));
-}
-
-PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t);
-
-PTD_INLINE bool scan_sphere(const DGeom& g, V3 o, V3 d, const RayF& rf, double& t) {
-    t = 0.0;
-    if (__builtin_amdgcn_ballot_w64(!sphere_impossible(rf, g.fcx, g.fcy, g.fcz, g.fr2)) == 0) return false;
-    return scan_sphere_exact(g, o, d, t);
 }
 
 PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t) {
