@@ -47,6 +47,7 @@ struct ProfScope {
 #endif
 
 constexpr int kMaxDepth = 5;  // trace() returns at n > 4: main.cpp:368
+constexpr int kGroupBodies = 8;  // member slots per group of the grouped scan
 constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
 enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4 };  // 2..4: device-only, normal = +-e_k
@@ -187,7 +188,13 @@ struct DScreen2 {
 
 struct DScene {
     const DGeom* geom;
-    const DScreen2* screen;  // ceil(n/2) records
+    // Grouped layout of the LDS-tiled scan: n_groups groups of kGroupBodies member slots
+    // (n_groups is even); bounds and members are float (centre, r^2) records, two per DScreen2;
+    // grp_order[slot] is the body index of a member slot (-1: padding).
+    const DScreen2* grp_bounds;
+    const DScreen2* grp_members;
+    const int32_t* grp_order;
+    int32_t n_groups;
     // Compact lists of the fused scan (body index in pad[0]): the planes that belong to no slab;
     // the spheres padded to an even count with a record whose screen can never pass, and the
     // spheres' paired screen records.
@@ -609,6 +616,19 @@ PTD_INLINE V3 brdf_lookup(const double* __restrict__ table, double theta_in, dou
 PTD_INLINE void vector_to_spherical(V3 in, double& theta, double& phi) {
     theta = atan(in.y / in.x);
     phi = acos(in.z / sqrt(in.x * in.x + in.y * in.y + in.z * in.z));
+}
+
+// Bounding-sphere screen of two groups: a member can only be hit when the ray starts inside the
+// bound (c < 0) or meets it ahead (disc >= 0 and b < 0); evaluated in float with the error bounds
+// of make_rayf (e_disc also bounds the error of c).  R^2 = +inf always passes, -inf never.
+PTD_INLINE void group_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
+                                      float e_b, const DScreen2& sc, lanemask& m0, lanemask& m1) {
+    f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
+    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
+    f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
+    f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
+    m0 = PTD_MASK(!(cf.x > e_disc)) | (PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b)));
+    m1 = PTD_MASK(!(cf.y > e_disc)) | (PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b)));
 }
 
 // ---- the estimator ---------------------------------------------------------------------

@@ -23,7 +23,6 @@ namespace ptw {
 using namespace ptd;
 
 constexpr int kWfBlock = 256;
-constexpr int kTileBodies = 1024;  // 1024 x 16 B of screening records = 16 KiB of LDS per block
 
 struct WfState {
     double* ray;     // [6][cap]  origin xyz, direction xyz
@@ -77,71 +76,83 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
     a[(size_t)(first + 2) * cap + p] = v.z;
 }
 
-// Nearest-hit scan with the body list staged through LDS in tiles of kTileBodies bodies.  A tile
-// holds the 32-byte screening records (float sphere data of two consecutive bodies).  Per four
-// bodies a wave reads two screening records (broadcast LDS reads) and runs the packed float screen;
-// only when some lane might hit does it fetch the full 64-byte record (scalar load at a
-// wave-uniform address) and evaluate in FP64.  In a scene of many small spheres almost every
-// (wave, body) pair ends at the screen, which keeps the LDS pipe and the FP64 units free.
+// Nearest-hit scan of large scenes.  Bodies are arranged in spatially compact groups of
+// kGroupBodies (built at upload, spheres along a Morton curve).  The float screening records of
+// a tile of groups (group bounds and member spheres, 16 B each) are staged once per block
+// through LDS.  Per pair of groups a wave runs the packed bounding-sphere screen (broadcast LDS
+// reads); only the groups some lane's ray might enter have their members screened, four per step;
+// and only a member some lane might hit is evaluated in FP64 from its full 64-byte record
+// (scalar loads at wave-uniform addresses).  The bound screen is valid for |d| <= 1 — a hit by
+// the reference's formula b < 0, b^2 > |D|^2 - r^2 then implies |o - c_B|_Q < R in the norm
+// |v|_Q^2 = |v|^2 - (v.d)^2, and an origin outside the bound has the bound's centre ahead —
+// so lanes with a longer direction examine every group.  Results are merged with the explicit
+// rule (t < mint) || (t == mint && index > hit), which makes them independent of the order.
 // Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
-// Same acceptance rule and body order as the reference scan.
+constexpr int kTileGroups = 128;  // 128 bounds + 1024 members, 16 B each: 18 KiB of LDS per block
 struct TileLds {
-    DScreen2 scr[kTileBodies / 2];
+    DScreen2 bounds[kTileGroups / 2];
+    DScreen2 members[kTileGroups * kGroupBodies / 2];
 };
 
-PTD_INLINE int nearest_hit_tiled(const DGeom* __restrict__ geom, const DScreen2* __restrict__ screen, int n, V3 o, V3 d,
-                                 int skip, bool active, float c1max, float r2max, TileLds* tile, double& tmin) {
-    const RayF rf = make_rayf(o, d, c1max, r2max);
+PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool active, TileLds* tile, double& tmin) {
+    const DGeom* __restrict__ geom = S.geom;
+    const int32_t* __restrict__ order = S.grp_order;
+    const RayF rf = make_rayf(o, d, S.sphere_c1max, S.sphere_r2max);
     const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
     const float e_disc = rf.e_disc, e_b = rf.e_b;
+    const lanemask long_dir = PTD_MASK(!(fdx * fdx + fdy * fdy + fdz * fdz <= 1.000001f));
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    for (int base = 0; base < n; base += kTileBodies) {
-        const int cnt = min(kTileBodies, n - base);
+    const int n_groups = S.n_groups;
+    for (int base = 0; base < n_groups; base += kTileGroups) {
+        const int cnt = min(kTileGroups, n_groups - base);  // even
         __syncthreads();  // the previous tile has been consumed by every wave
         {
-            const uint4* ssrc = reinterpret_cast<const uint4*>(screen + base / 2);
-            uint4* sdst = reinterpret_cast<uint4*>(tile->scr);
-            const int have = ((cnt + 1) / 2) * 2;    // uint4 units present in global memory
-            const int want = ((cnt + 3) / 4) * 4;    // uint4 units the screening loop reads
-            for (int k = threadIdx.x; k < want; k += blockDim.x)
-                sdst[k] = k < have ? ssrc[k] : make_uint4(0u, 0u, 0u, 0u);  // r2 = 0 at the origin: harmless, index >= cnt is never examined
+            const uint4* bsrc = reinterpret_cast<const uint4*>(S.grp_bounds + base / 2);
+            uint4* bdst = reinterpret_cast<uint4*>(tile->bounds);
+            for (int k = threadIdx.x; k < cnt; k += blockDim.x) bdst[k] = bsrc[k];  // 16 B per lane, coalesced
+            const uint4* msrc = reinterpret_cast<const uint4*>(S.grp_members + (size_t)base * kGroupBodies / 2);
+            uint4* mdst = reinterpret_cast<uint4*>(tile->members);
+            for (int k = threadIdx.x; k < cnt * kGroupBodies; k += blockDim.x) mdst[k] = msrc[k];
         }
         __syncthreads();
         if (active) {
-            // four bodies (two screening records) per step; the records past the tile's end were
-            // filled with inconclusive-free padding by the loader below
-            const int steps = (cnt + 3) / 4;
-            for (int q = 0; q < steps; ++q) {
-                const DScreen2 sa = tile->scr[2 * q];  // same address in every lane: LDS broadcast
-                const DScreen2 sb = tile->scr[2 * q + 1];
-                // per body, the lanes that need the exact test (wave masks on the scalar unit)
-                lanemask need[4];
-                sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
-                sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
-                if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
-                const unsigned bodies = (need[0] != 0 ? 1u : 0u) | (need[1] != 0 ? 2u : 0u) | (need[2] != 0 ? 4u : 0u) |
-                                        (need[3] != 0 ? 8u : 0u);
+            for (int gp = 0; gp < cnt / 2; ++gp) {
+                lanemask enter[2];
+                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tile->bounds[gp], enter[0], enter[1]);
+                if (((enter[0] | enter[1] | long_dir)) == 0) continue;
 #pragma unroll 1
-                for (int h = 0; h < 4; ++h) {
-                    if (!((bodies >> h) & 1u)) continue;
-                    const int i = 4 * q + h;
-                    if (i >= cnt) break;
-                    const DGeom g = geom[base + i];  // wave-uniform address: scalar load, rare
-                    const int shape = g.shape;
-                    double t;
-                    bool ok;
-                    switch (shape) {
-                        case kSphere: ok = scan_sphere_exact(g, o, d, t); break;
-                        case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
-                        case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
-                        case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
-                        default: ok = scan_plane(g, o, d, t); break;
+                for (int side = 0; side < 2; ++side) {
+                    if ((enter[side] | long_dir) == 0) continue;
+                    const int g = 2 * gp + side;
+#pragma unroll 1
+                    for (int q = 0; q < kGroupBodies / 4; ++q) {
+                        const DScreen2 sa = tile->members[g * (kGroupBodies / 2) + 2 * q];  // LDS broadcast
+                        const DScreen2 sb = tile->members[g * (kGroupBodies / 2) + 2 * q + 1];
+                        lanemask need[4];
+                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
+                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
+                        if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
+                        const unsigned bodies = (need[0] != 0 ? 1u : 0u) | (need[1] != 0 ? 2u : 0u) |
+                                                (need[2] != 0 ? 4u : 0u) | (need[3] != 0 ? 8u : 0u);
+#pragma unroll 1
+                        for (int h = 0; h < 4; ++h) {
+                            if (!((bodies >> h) & 1u)) continue;
+                            const int idx = order[(size_t)(base + g) * kGroupBodies + 4 * q + h];  // scalar load, rare
+                            if (idx < 0) continue;
+                            const DGeom gm = geom[idx];
+                            double t;
+                            bool ok;
+                            switch (gm.shape) {
+                                case kSphere: ok = scan_sphere_exact(gm, o, d, t); break;
+                                case kPlaneX: ok = scan_plane_axis(gm.cx, o.x, d.x, t); break;
+                                case kPlaneY: ok = scan_plane_axis(gm.cy, o.y, d.y, t); break;
+                                case kPlaneZ: ok = scan_plane_axis(gm.cz, o.z, d.z, t); break;
+                                default: ok = scan_plane(gm, o, d, t); break;
+                            }
+                            merge_hit(ok, t, idx, skip, hit, mint);
+                        }
                     }
-                    const int idx = base + i;
-                    bool take = ok && (t > 0.0) && (t <= mint) && (idx != skip);
-                    mint = take ? t : mint;
-                    hit = take ? idx : hit;
                 }
             }
         }
@@ -215,7 +226,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int
         }
     }
     double mint;
-    int hit = nearest_hit_tiled(S.geom, S.screen, S.n_bodies, o, d, skip, active, S.sphere_c1max, S.sphere_r2max, &s_tile, mint);
+    int hit = nearest_hit_tiled(S, o, d, skip, active, &s_tile, mint);
     if (active) {
         W.hit[p] = hit;
         W.t[p] = mint;

@@ -373,7 +373,8 @@ struct pt_scene {
     std::vector<int32_t> lights;
     Partition part;
     DScene ds;
-    DevBuf d_geom, d_mat, d_screen, d_lights, d_brdf[PT_MAX_BRDF];
+    DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
+    DevBuf d_grp_members, d_grp_bounds, d_grp_order;
     DevBuf d_scan_planes, d_scan_spheres, d_scan_screen;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
@@ -447,11 +448,6 @@ int upload_scene(pt_scene* s) {
     const int n = (int)s->bodies.size();
     std::vector<DGeom> geom(n);
     std::vector<DMat> mat(n);
-    std::vector<DScreen2> scr((n + 1) / 2);
-    for (auto& r : scr) {
-        r.cx = r.cy = r.cz = f32x2{0.0f, 0.0f};
-        r.r2 = f32x2{std::nanf(""), std::nanf("")};
-    }
     float c1max = 0.0f, r2max = 0.0f;
     for (int i = 0; i < n; ++i) {
         const pt_body& b = s->bodies[i];
@@ -480,13 +476,6 @@ int upload_scene(pt_scene* s) {
             r2max = std::max(r2max, g.fr2);
         }
         geom[i] = g;
-        if (b.shape == PT_SPHERE) {
-            DScreen2& r = scr[i / 2];
-            r.cx[i & 1] = g.fcx;
-            r.cy[i & 1] = g.fcy;
-            r.cz[i & 1] = g.fcz;
-            r.r2[i & 1] = g.fr2;
-        }
         DMat m;
         memset(&m, 0, sizeof m);
         m.colr = b.color[0];
@@ -558,6 +547,109 @@ int upload_scene(pt_scene* s) {
         r.cz[k & 1] = scan_spheres[k].fcz;
         r.r2[k & 1] = scan_spheres[k].fr2;
     }
+    // Grouped layout of the LDS-tiled scan (wavefront pipeline): bodies in groups of kGroupBodies,
+    // spheres ordered along a Morton curve so that a group is spatially compact.  Per group a
+    // bounding sphere in float (centre, R^2 rounded outwards): a wave examines the members only when
+    // some lane's ray might enter the bound.  Planes form leading groups whose bound always passes
+    // (R^2 = +inf).  Member records are the float (centre, r^2) pairs of the per-body screen; slots
+    // past the end can never pass (r^2 = -inf).  grp_order maps member slots to body indices.
+    std::vector<int32_t> order;
+    {
+        std::vector<int> sph;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; ++i) {
+            if (geom[i].shape != kSphere) {
+                order.push_back(i);
+            } else {
+                sph.push_back(i);
+                const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = std::min(lo[k], c[k]);
+                    hi[k] = std::max(hi[k], c[k]);
+                }
+            }
+        }
+        while (order.size() % kGroupBodies) order.push_back(-1);
+        const int plane_groups = (int)order.size() / kGroupBodies;
+        auto morton = [&](int i) {
+            const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
+            uint64_t code = 0;
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                double u = hi[k] > lo[k] ? (c[k] - lo[k]) / (hi[k] - lo[k]) : 0.0;
+                if (!(u >= 0.0)) u = 0.0;  // also NaN
+                if (u > 1.0) u = 1.0;
+                q[k] = (uint32_t)(u * 1023.0);
+            }
+            for (int bit = 9; bit >= 0; --bit)
+                for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> bit) & 1u);
+            return code;
+        };
+        std::vector<std::pair<uint64_t, int>> keyed;
+        for (int i : sph) keyed.push_back({morton(i), i});
+        std::sort(keyed.begin(), keyed.end());
+        for (auto& kv : keyed) order.push_back(kv.second);
+        while (order.size() % (2 * kGroupBodies)) order.push_back(-1);  // an even number of groups
+        const int n_groups = (int)order.size() / kGroupBodies;
+        std::vector<DScreen2> members(order.size() / 2), bounds(n_groups / 2);
+        for (size_t k = 0; k < order.size(); ++k) {
+            DScreen2& r = members[k / 2];
+            const int i = order[k];
+            const bool sphere = i >= 0 && geom[i].shape == kSphere;
+            // non-spheres are always examined (an all-NaN record never screens out), padding never
+            const float other = i >= 0 ? std::nanf("") : 0.0f;
+            r.cx[k & 1] = sphere ? geom[i].fcx : other;
+            r.cy[k & 1] = sphere ? geom[i].fcy : other;
+            r.cz[k & 1] = sphere ? geom[i].fcz : other;
+            r.r2[k & 1] = sphere ? geom[i].fr2 : (i >= 0 ? std::nanf("") : -INFINITY);
+        }
+        for (int g = 0; g < n_groups; ++g) {
+            DScreen2& r = bounds[g / 2];
+            double c[3] = {0.0, 0.0, 0.0};
+            int cnt = 0;
+            for (int k = 0; k < kGroupBodies; ++k) {
+                const int i = order[(size_t)g * kGroupBodies + k];
+                if (i < 0) continue;
+                c[0] += geom[i].cx;
+                c[1] += geom[i].cy;
+                c[2] += geom[i].cz;
+                cnt++;
+            }
+            float fc[3] = {0.0f, 0.0f, 0.0f};
+            float fr2 = -INFINITY;  // empty group: never entered
+            if (g < plane_groups && cnt > 0) {
+                fr2 = INFINITY;
+            } else if (cnt > 0) {
+                for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
+                double R = 0.0;  // measured from the float centre actually stored
+                for (int k = 0; k < kGroupBodies; ++k) {
+                    const int i = order[(size_t)g * kGroupBodies + k];
+                    if (i < 0) continue;
+                    const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
+                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
+                }
+                fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
+                if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
+                c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
+                if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+            }
+            r.cx[g & 1] = fc[0];
+            r.cy[g & 1] = fc[1];
+            r.cz[g & 1] = fc[2];
+            r.r2[g & 1] = fr2;
+        }
+        int rcg;
+        if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
+        if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
+        if ((rcg = s->d_grp_order.ensure(sizeof(int32_t) * order.size()))) return rcg;
+        HIP_TRY(hipMemcpy(s->d_grp_members.p, members.data(), sizeof(DScreen2) * members.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_grp_bounds.p, bounds.data(), sizeof(DScreen2) * bounds.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_grp_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+        D.grp_members = (const DScreen2*)s->d_grp_members.p;
+        D.grp_bounds = (const DScreen2*)s->d_grp_bounds.p;
+        D.grp_order = (const int32_t*)s->d_grp_order.p;
+        D.n_groups = n_groups;
+    }
     if (scan_planes.empty()) scan_planes.resize(1);
     if (scan_spheres.empty()) scan_spheres.resize(2);
     if (scan_screen.empty()) scan_screen.resize(1);
@@ -570,16 +662,13 @@ int upload_scene(pt_scene* s) {
     HIP_TRY(hipMemcpy(s->d_scan_screen.p, scan_screen.data(), sizeof(DScreen2) * scan_screen.size(), hipMemcpyHostToDevice));
     if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
     if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
-    if ((rc = s->d_screen.ensure(sizeof(DScreen2) * scr.size()))) return rc;
     if ((rc = s->d_lights.ensure(sizeof(int32_t) * std::max<size_t>(1, s->lights.size())))) return rc;
     HIP_TRY(hipMemcpy(s->d_geom.p, geom.data(), sizeof(DGeom) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_mat.p, mat.data(), sizeof(DMat) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_screen.p, scr.data(), sizeof(DScreen2) * scr.size(), hipMemcpyHostToDevice));
     if (!s->lights.empty())
         HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), sizeof(int32_t) * s->lights.size(), hipMemcpyHostToDevice));
     D.geom = (const DGeom*)s->d_geom.p;
     D.mat = (const DMat*)s->d_mat.p;
-    D.screen = (const DScreen2*)s->d_screen.p;
     D.lights = (const int32_t*)s->d_lights.p;
     D.scan_planes = (const DGeom*)s->d_scan_planes.p;
     D.scan_spheres = (const DGeom*)s->d_scan_spheres.p;
@@ -756,7 +845,9 @@ int pt_scene_destroy(pt_scene* s) {
     (void)hipSetDevice(s->device);
     s->d_geom.release();
     s->d_mat.release();
-    s->d_screen.release();
+    s->d_grp_members.release();
+    s->d_grp_bounds.release();
+    s->d_grp_order.release();
     s->d_scan_planes.release();
     s->d_scan_spheres.release();
     s->d_scan_screen.release();
