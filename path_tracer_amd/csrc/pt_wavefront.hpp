@@ -41,16 +41,26 @@ struct WfState {
     size_t cap;
 };
 
-// Append `value` for every lane with `pred` set; one atomic per wave.  Call with the whole wave.
-PTD_INLINE void queue_push(int32_t* q, int32_t* count, bool pred, int value) {
-    unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
-    if (m == 0) return;
-    const int lane = __lane_id();
-    const int leader = __builtin_ctzll(m);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(count, (int)__builtin_popcountll(m));
-    base = __shfl(base, leader);
-    if (pred) q[base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = value;
+// Append `value` for every thread with `pred` set: one atomic per block (the four waves' counts
+// meet in LDS).  Every thread of a kWfBlock-thread block must call it; `slots` is two words of LDS
+// per wave.  The order of a queue is arbitrary; no result depends on it.
+PTD_INLINE void queue_push(int32_t* q, int32_t* count, bool pred, int value, int32_t* slots) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // `slots` may still be read from the previous push
+    if (lane == 0) slots[wave] = (int)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < kWfBlock / 64; ++w) {
+            const int c = slots[w];
+            slots[w] = total;  // exclusive prefix inside the block
+            total += c;
+        }
+        slots[kWfBlock / 64] = total ? atomicAdd(count, total) : 0;
+    }
+    __syncthreads();
+    if (pred) q[slots[kWfBlock / 64] + slots[wave] + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = value;
 }
 
 PTD_INLINE Rng load_rng(const WfState& W, size_t p) {
@@ -88,7 +98,7 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 // so lanes with a longer direction examine every group.  Results are merged with the explicit
 // rule (t < mint) || (t == mint && index > hit), which makes them independent of the order.
 // Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
-constexpr int kTileGroups = 128;  // 128 bounds + 1024 members, 16 B each: 18 KiB of LDS per block
+constexpr int kTileGroups = 1024 / kGroupBodies;  // bounds + 1024 members, 16 B each: <= 18 KiB of LDS per block
 struct TileLds {
     DScreen2 bounds[kTileGroups / 2];
     DScreen2 members[kTileGroups * kGroupBodies / 2];
@@ -195,7 +205,8 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         W.need[p] = 0;
         store3(W.L, W.cap, p, 0, mk(0.0, 0.0, 0.0));
     }
-    queue_push(W.queue, W.qcount, valid, (int)p);
+    __shared__ int32_t s_push[kWfBlock / 64 + 1];
+    queue_push(W.queue, W.qcount, valid, (int)p, s_push);
 }
 
 enum { kGather = 0, kShadow = 1 };
@@ -260,7 +271,8 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int 
             store_rng(W, p, dr.rng);
         }
     }
-    queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p);
+    __shared__ int32_t s_push[kWfBlock / 64 + 1];
+    queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
 }
 
 constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks of vertex 0
@@ -285,8 +297,9 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_light(DScene S, WfState W) {
         store_rng(W, p, dr.rng);
         tasks = S.nee_emission_only ? W.need[p] : W.nrec[p];
     }
+    __shared__ int32_t s_push[kWfBlock / 64 + 1];
     for (int g = 0; g < kMaxDepth; ++g)
-        queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, tasks > g, (int)p);
+        queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, tasks > g, (int)p, s_push);
 }
 
 // NEE vertex gi for the paths of its shadow-task queue.
