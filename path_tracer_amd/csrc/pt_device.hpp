@@ -195,6 +195,7 @@ struct DScene {
     const DScreen2* grp_members;
     const int32_t* grp_order;
     int32_t n_groups;
+    float sort_mid[3], sort_inv[3];  // origin cells of the ray sort: cell coordinate = (o - mid) * inv in [-1, 1]
     // Compact lists of the fused scan (body index in pad[0]): the planes that belong to no slab;
     // the spheres padded to an even count with a record whose screen can never pass, and the
     // spheres' paired screen records.

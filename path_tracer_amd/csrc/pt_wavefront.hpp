@@ -38,6 +38,9 @@ struct WfState {
     int32_t* need;   // [cap]     1 + deepest emitting vertex (scenes with a dead direct term), else 0
     int32_t* queue;  // [11][cap] 0..5: paths with more than d-1 records; 6..10: shadow tasks of vertex 0..4
     int32_t* qcount; // [16]
+    int32_t* sorted; // [cap]     a queue reordered by ray key (see k_wf_sort_*)
+    uint32_t* keys;  // [cap]
+    uint32_t* bins;  // [kSortBins] histogram, then running offsets
     size_t cap;
 };
 
@@ -211,9 +214,120 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
 
 enum { kGather = 0, kShadow = 1 };
 
+
+constexpr int kSortBins = 1 << 16;
+
+// The ray of entry i of queue qi: the path's current ray, or the shadow ray towards vertex gi.
+template <int MODE>
+PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V3& o, V3& d, int& skip) {
+    if (MODE == kGather) {
+        o = load3(W.ray, W.cap, p, 0);
+        d = load3(W.ray, W.cap, p, 3);
+        skip = -1;
+    } else {
+        const int light = W.light[p];
+        const V3 lc = light_origin(S, light);
+        V3 Pt = load3(W.pts, W.cap, p, gi * 3);
+        o = lc;
+        d = normalize(sub(Pt, lc));  // next_event.cpp:405-407
+        skip = light;
+    }
+}
+
+// Rays are reordered before a scan so that the 64 rays of a wave start near one another and
+// point the same way: a wave then enters few of the body groups.  The key is a cell of the
+// direction (cube face, 8x8; the major part: measured to matter more) and a coarse cell of the
+// origin (5x5x5 over the scene's box); shadow rays, which share their origin, use a fine
+// direction cell (cube face, 64x64).  One counting sort per
+// scan: histogram, exclusive scan, scatter.  The order inside a bin is arbitrary and, like the
+// order of a queue, invisible in the results.
+PTD_INLINE uint32_t grid_cell(float u, int cells) {  // u in [-1, 1] -> 0..cells-1, NaN -> 0
+    int c = (int)((u + 1.0f) * (0.5f * (float)cells));
+    c = c < cells - 1 ? c : cells - 1;
+    return (uint32_t)(c > 0 ? c : 0);
+}
+template <int MODE>
+PTD_INLINE uint32_t ray_key(const DScene& S, V3 o, V3 d) {
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float ax = __builtin_fabsf(dx), ay = __builtin_fabsf(dy), az = __builtin_fabsf(dz);
+    uint32_t face;
+    float u, v, m;
+    if (ax >= ay && ax >= az) {
+        face = dx < 0.0f ? 1u : 0u;
+        m = ax;
+        u = dy;
+        v = dz;
+    } else if (ay >= az) {
+        face = dy < 0.0f ? 3u : 2u;
+        m = ay;
+        u = dx;
+        v = dz;
+    } else {
+        face = dz < 0.0f ? 5u : 4u;
+        m = az;
+        u = dx;
+        v = dy;
+    }
+    const float inv = m > 0.0f ? 1.0f / m : 0.0f;
+    if (MODE == kShadow) return (face * 64u + grid_cell(v * inv, 64)) * 64u + grid_cell(u * inv, 64);  // < 24576
+    const uint32_t dir = (face * 8u + grid_cell(v * inv, 8)) * 8u + grid_cell(u * inv, 8);  // < 384
+    const uint32_t cx = grid_cell(((float)o.x - S.sort_mid[0]) * S.sort_inv[0], 5);
+    const uint32_t cy = grid_cell(((float)o.y - S.sort_mid[1]) * S.sort_inv[1], 5);
+    const uint32_t cz = grid_cell(((float)o.z - S.sort_mid[2]) * S.sort_inv[2], 5);
+    return (dir << 7) | ((cz * 5u + cy) * 5u + cx);  // < 49152
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kWfBlock) k_wf_sort_keys(DScene S, WfState W, int qi, int gi) {
+    const int count = W.qcount[qi];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if (i >= count) return;
+    const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
+    V3 o, d;
+    int skip;
+    queue_ray<MODE>(S, W, p, gi, o, d, skip);
+    const uint32_t key = ray_key<MODE>(S, o, d);
+    W.keys[i] = key;
+    atomicAdd(&W.bins[key], 1u);
+}
+
+// Exclusive prefix sum of the kSortBins counters, one block of 1024 threads.
+__global__ void __launch_bounds__(1024) k_wf_sort_scan(WfState W) {
+    __shared__ uint32_t s_part[1024];
+    constexpr int kPer = kSortBins / 1024;
+    const int t = threadIdx.x;
+    uint32_t local[kPer];
+    uint32_t sum = 0;
+    for (int k = 0; k < kPer; ++k) {
+        local[k] = W.bins[t * kPer + k];
+        sum += local[k];
+    }
+    s_part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = t >= off ? s_part[t - off] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[t] - sum;
+    for (int k = 0; k < kPer; ++k) {
+        W.bins[t * kPer + k] = run;
+        run += local[k];
+    }
+}
+
+__global__ void __launch_bounds__(kWfBlock) k_wf_sort_scatter(WfState W, int qi) {
+    const int count = W.qcount[qi];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t pos = atomicAdd(&W.bins[W.keys[i]], 1u);
+    W.sorted[pos] = W.queue[(size_t)qi * W.cap + i];
+}
+
 // One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.
 template <int MODE>
-__global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int qi, int gi) {
+__global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ list) {
     __shared__ TileLds s_tile;
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
@@ -223,18 +337,8 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int
     V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 1.0);
     int skip = -1;
     if (active) {
-        p = (size_t)W.queue[(size_t)qi * W.cap + i];
-        if (MODE == kGather) {
-            o = load3(W.ray, W.cap, p, 0);
-            d = load3(W.ray, W.cap, p, 3);
-        } else {
-            const int light = W.light[p];
-            const V3 lc = light_origin(S, light);
-            V3 Pt = load3(W.pts, W.cap, p, gi * 3);
-            o = lc;
-            d = normalize(sub(Pt, lc));  // next_event.cpp:405-407
-            skip = light;
-        }
+        p = (size_t)list[i];  // queue qi, possibly reordered
+        queue_ray<MODE>(S, W, p, gi, o, d, skip);
     }
     double mint;
     int hit = nearest_hit_tiled(S, o, d, skip, active, &s_tile, mint);

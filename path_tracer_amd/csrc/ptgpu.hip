@@ -387,6 +387,7 @@ struct pt_scene {
     std::vector<hipEvent_t> ev;  // start/stop pairs of the estimator launches of the last render
     size_t ev_used = 0;
     double last_paths = 0;
+    bool wf_sort = true;        // wavefront pipeline: reorder rays by key before every scan
     bool has_measured = false;  // any PT_MEASURED body: selects the kernel variant with the table lookup
     int pipeline = PT_PIPELINE_AUTO;
     int wf_batch = 1;  // iterations per wavefront batch
@@ -649,6 +650,11 @@ int upload_scene(pt_scene* s) {
         D.grp_bounds = (const DScreen2*)s->d_grp_bounds.p;
         D.grp_order = (const int32_t*)s->d_grp_order.p;
         D.n_groups = n_groups;
+        for (int k = 0; k < 3; ++k) {  // box of the sphere centres (the whole scene when there are none)
+            const bool any = hi[k] > lo[k];
+            D.sort_mid[k] = any ? (float)(0.5 * (lo[k] + hi[k])) : 0.0f;
+            D.sort_inv[k] = any ? (float)(2.0 / (hi[k] - lo[k])) : 1.0f;
+        }
     }
     if (scan_planes.empty()) scan_planes.resize(1);
     if (scan_spheres.empty()) scan_spheres.resize(2);
@@ -711,8 +717,9 @@ int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     const size_t cap = J * (size_t)s->wf_batch;
     if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
-    // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, need 1, queue 11 = 24
-    size_t bytes = cap * (27 * sizeof(double) + 24 * sizeof(int32_t)) + 64;
+    // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, need 1,
+    // queue 11, sorted 1, keys 1 = 26; plus the 16 queue counters and the kSortBins sort counters
+    size_t bytes = cap * (27 * sizeof(double) + 26 * sizeof(int32_t)) + (16 + ptw::kSortBins) * sizeof(int32_t);
     int rc = s->d_wf.ensure(bytes);
     if (rc) return rc;
     ptw::WfState& W = s->wf;
@@ -732,6 +739,9 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.need = W.light + cap;
     W.queue = W.need + cap;
     W.qcount = W.queue + 11 * cap;
+    W.sorted = W.qcount + 16;
+    W.keys = (uint32_t*)(W.sorted + cap);
+    W.bins = W.keys + cap;
     W.cap = cap;
     return PT_OK;
 }
@@ -745,14 +755,29 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const int nblk = (int)((J * (size_t)B + kWfBlock - 1) / kWfBlock);
     HIP_TRY(hipMemsetAsync(W.qcount, 0, 16 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
+    // the rays of a queue are put in key order before the scan (not the primary rays, which
+    // leave k_wf_generate in pixel order)
+    auto sorted_list = [&](int mode, int qi, int gi) -> const int32_t* {
+        if (!s->wf_sort) return W.queue + (size_t)qi * W.cap;
+        (void)hipMemsetAsync(W.bins, 0, kSortBins * sizeof(uint32_t), st);  // errors surface at hipGetLastError below
+        if (mode == kGather)
+            hipLaunchKernelGGL((k_wf_sort_keys<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi);
+        else
+            hipLaunchKernelGGL((k_wf_sort_keys<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi);
+        hipLaunchKernelGGL(k_wf_sort_scan, dim3(1), dim3(1024), 0, st, W);
+        hipLaunchKernelGGL(k_wf_sort_scatter, dim3(nblk), dim3(kWfBlock), 0, st, W, qi);
+        return W.sorted;
+    };
     for (int depth = 0; depth < kMaxDepth; ++depth) {
-        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, 0);
+        const int32_t* list = depth == 0 ? W.queue : sorted_list(kGather, depth, 0);
+        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, 0, list);
         hipLaunchKernelGGL(k_wf_shade, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, depth);
     }
     if (s->estimator == PT_EST_NEE) {
         hipLaunchKernelGGL(k_wf_light, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W);
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
-            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi);
+            const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi);
+            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list);
             if (s->has_measured)
                 hipLaunchKernelGGL((k_wf_nee<true, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
             else
