@@ -396,35 +396,38 @@ PTD_INLINE void merge_sphere(const DGeom& g, V3 o, V3 d, int skip, int& hit, dou
     bool ok = scan_sphere_exact(g, o, d, t);
     merge_hit(ok, t, g.pad[0], skip, hit, mint);
 }
+// Steps 1 and 2 of the scan: the planes outside the slabs, then the slabs.
+PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ planes, V3 o, V3 d, int skip, int& hit,
+                                double& mint) {
+    PT_PROF(kProfScanPlanes);
+    const int n_planes = S.n_planes;
+    for (int k = 0; k < n_planes; ++k) {
+        const DGeom g = planes[k];
+        double t;
+        bool ok;
+        switch (g.shape) {
+            case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
+            case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
+            case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
+            default: ok = scan_plane(g, o, d, t); break;
+        }
+        const int i = g.pad[0];
+        bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
+        mint = take ? t : mint;
+        hit = take ? i : hit;
+    }
+    if (S.slab_mask & 1)
+        scan_slab(S.slab_lo[0], S.slab_hi[0], S.slab_big[0], S.slab_ilo[0], S.slab_ihi[0], o.x, d.x, skip, hit, mint);
+    if (S.slab_mask & 2)
+        scan_slab(S.slab_lo[1], S.slab_hi[1], S.slab_big[1], S.slab_ilo[1], S.slab_ihi[1], o.y, d.y, skip, hit, mint);
+    if (S.slab_mask & 4)
+        scan_slab(S.slab_lo[2], S.slab_hi[2], S.slab_big[2], S.slab_ilo[2], S.slab_ihi[2], o.z, d.z, skip, hit, mint);
+}
 PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ planes, const DGeom* __restrict__ spheres,
                                  const DScreen2* __restrict__ screen, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    {
-        PT_PROF(kProfScanPlanes);
-        const int n_planes = S.n_planes;
-        for (int k = 0; k < n_planes; ++k) {
-            const DGeom g = planes[k];
-            double t;
-            bool ok;
-            switch (g.shape) {
-                case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
-                case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
-                case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
-                default: ok = scan_plane(g, o, d, t); break;
-            }
-            const int i = g.pad[0];
-            bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
-            mint = take ? t : mint;
-            hit = take ? i : hit;
-        }
-        if (S.slab_mask & 1)
-            scan_slab(S.slab_lo[0], S.slab_hi[0], S.slab_big[0], S.slab_ilo[0], S.slab_ihi[0], o.x, d.x, skip, hit, mint);
-        if (S.slab_mask & 2)
-            scan_slab(S.slab_lo[1], S.slab_hi[1], S.slab_big[1], S.slab_ilo[1], S.slab_ihi[1], o.y, d.y, skip, hit, mint);
-        if (S.slab_mask & 4)
-            scan_slab(S.slab_lo[2], S.slab_hi[2], S.slab_big[2], S.slab_ilo[2], S.slab_ihi[2], o.z, d.z, skip, hit, mint);
-    }
+    scan_all_planes(S, planes, o, d, skip, hit, mint);
     const int n_spheres = S.n_spheres;
     if (n_spheres > 0) {
         PT_PROF(kProfScanScreen);

@@ -89,17 +89,20 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
     a[(size_t)(first + 2) * cap + p] = v.z;
 }
 
-// Nearest-hit scan of large scenes.  Bodies are arranged in spatially compact groups of
-// kGroupBodies (built at upload, spheres along a Morton curve).  The float screening records of
-// a tile of groups (group bounds and member spheres, 16 B each) are staged once per block
-// through LDS.  Per pair of groups a wave runs the packed bounding-sphere screen (broadcast LDS
-// reads); only the groups some lane's ray might enter have their members screened, four per step;
-// and only a member some lane might hit is evaluated in FP64 from its full 64-byte record
-// (scalar loads at wave-uniform addresses).  The bound screen is valid for |d| <= 1 — a hit by
-// the reference's formula b < 0, b^2 > |D|^2 - r^2 then implies |o - c_B|_Q < R in the norm
-// |v|_Q^2 = |v|^2 - (v.d)^2, and an origin outside the bound has the bound's centre ahead —
-// so lanes with a longer direction examine every group.  Results are merged with the explicit
-// rule (t < mint) || (t == mint && index > hit), which makes them independent of the order.
+// Nearest-hit scan of large scenes.  Planes are scanned first, exactly as in the fused kernel.
+// The spheres are arranged in spatially compact groups of kGroupBodies (built at upload, along a
+// Morton curve).  The float screening records of a tile of groups (group bounds and member
+// spheres, 16 B each) are staged once per block through LDS.  Per pair of groups a wave runs the
+// packed bounding-sphere screen (broadcast LDS reads); only the groups some lane's ray might enter
+// have their members screened, four per step; a lane whose screen of a member is inconclusive
+// notes the member's slot in a four-entry list of its own, and whenever some lane's list is full
+// every lane evaluates its noted members in FP64 from the full records (per-lane loads).  So the
+// FP64 work is per lane, not per wave: a wave of 64 unrelated rays meets some 200 members, a lane
+// three or four.  The bound screen is valid for |d| <= 1 — a hit by the reference's formula
+// b < 0, b^2 > |D|^2 - r^2 then implies |o - c_B|_Q < R in the norm |v|_Q^2 = |v|^2 - (v.d)^2, and
+// an origin outside the bound has the bound's centre ahead — so lanes with a longer direction
+// examine every group.  Results are merged with the explicit rule
+// (t < mint) || (t == mint && index > hit), which makes them independent of the order.
 // Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
 constexpr int kTileGroups = 1024 / kGroupBodies;  // bounds + 1024 members, 16 B each: <= 18 KiB of LDS per block
 struct TileLds {
@@ -107,15 +110,45 @@ struct TileLds {
     DScreen2 members[kTileGroups * kGroupBodies / 2];
 };
 
-PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool active, TileLds* tile, double& tmin) {
+// The members a lane has noted for exact evaluation (slots of the grouped layout).
+struct Pending {
+    uint32_t slot[4];
+    uint32_t n;
+};
+PTD_INLINE void pending_eval(const DScene& S, Pending& pd, V3 o, V3 d, int skip, int& hit, double& mint) {
     const DGeom* __restrict__ geom = S.geom;
     const int32_t* __restrict__ order = S.grp_order;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (__builtin_amdgcn_ballot_w64(pd.n > j) == 0) break;
+        if (pd.n > j) {
+            const int idx = order[pd.slot[j]];
+            if (idx < 0) continue;  // a padding slot, reachable only by a NaN ray
+            const DGeom* g = geom + idx;
+            DGeom s;
+            s.cx = g->cx;
+            s.cy = g->cy;
+            s.cz = g->cz;
+            s.nx = g->nx;
+            double t;
+            const bool ok = scan_sphere_exact(s, o, d, t);
+            merge_hit(ok, t, idx, skip, hit, mint);
+        }
+    }
+    pd.n = 0;
+}
+
+PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool active, TileLds* tile, double& tmin) {
     const RayF rf = make_rayf(o, d, S.sphere_c1max, S.sphere_r2max);
     const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
     const float e_disc = rf.e_disc, e_b = rf.e_b;
     const lanemask long_dir = PTD_MASK(!(fdx * fdx + fdy * fdy + fdz * fdz <= 1.000001f));
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
+    if (active) scan_all_planes(S, S.scan_planes, o, d, skip, hit, mint);
+    Pending pd;
+    pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
+    pd.n = 0u;
     const int n_groups = S.n_groups;
     for (int base = 0; base < n_groups; base += kTileGroups) {
         const int cnt = min(kTileGroups, n_groups - base);  // even
@@ -146,30 +179,23 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
                         sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
                         sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
                         if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
-                        const unsigned bodies = (need[0] != 0 ? 1u : 0u) | (need[1] != 0 ? 2u : 0u) |
-                                                (need[2] != 0 ? 4u : 0u) | (need[3] != 0 ? 8u : 0u);
-#pragma unroll 1
+#pragma unroll
                         for (int h = 0; h < 4; ++h) {
-                            if (!((bodies >> h) & 1u)) continue;
-                            const int idx = order[(size_t)(base + g) * kGroupBodies + 4 * q + h];  // scalar load, rare
-                            if (idx < 0) continue;
-                            const DGeom gm = geom[idx];
-                            double t;
-                            bool ok;
-                            switch (gm.shape) {
-                                case kSphere: ok = scan_sphere_exact(gm, o, d, t); break;
-                                case kPlaneX: ok = scan_plane_axis(gm.cx, o.x, d.x, t); break;
-                                case kPlaneY: ok = scan_plane_axis(gm.cy, o.y, d.y, t); break;
-                                case kPlaneZ: ok = scan_plane_axis(gm.cz, o.z, d.z, t); break;
-                                default: ok = scan_plane(gm, o, d, t); break;
-                            }
-                            merge_hit(ok, t, idx, skip, hit, mint);
+                            if (need[h] == 0) continue;
+                            const uint32_t slot = (uint32_t)((base + g) * kGroupBodies + 4 * q + h);
+                            // the lanes of need[h] append `slot` to their lists
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j)
+                                pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
+                            pd.n += sel32(need[h], 1u, 0u);
+                            if (PTD_MASK(pd.n == 4u) != 0) pending_eval(S, pd, o, d, skip, hit, mint);
                         }
                     }
                 }
             }
         }
     }
+    if (active) pending_eval(S, pd, o, d, skip, hit, mint);
     tmin = mint;
     return hit;
 }

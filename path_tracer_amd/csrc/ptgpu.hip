@@ -548,20 +548,18 @@ int upload_scene(pt_scene* s) {
         r.cz[k & 1] = scan_spheres[k].fcz;
         r.r2[k & 1] = scan_spheres[k].fr2;
     }
-    // Grouped layout of the LDS-tiled scan (wavefront pipeline): bodies in groups of kGroupBodies,
-    // spheres ordered along a Morton curve so that a group is spatially compact.  Per group a
+    // Grouped layout of the LDS-tiled scan (wavefront pipeline): the spheres in groups of
+    // kGroupBodies, ordered along a Morton curve so that a group is spatially compact.  Per group a
     // bounding sphere in float (centre, R^2 rounded outwards): a wave examines the members only when
-    // some lane's ray might enter the bound.  Planes form leading groups whose bound always passes
-    // (R^2 = +inf).  Member records are the float (centre, r^2) pairs of the per-body screen; slots
-    // past the end can never pass (r^2 = -inf).  grp_order maps member slots to body indices.
+    // some lane's ray might enter the bound.  Member records are the float (centre, r^2) pairs of
+    // the per-body screen; slots past the end can never pass (r^2 = -inf).  grp_order maps member
+    // slots to body indices.  (Planes are scanned from the plane list, as in the fused kernel.)
     std::vector<int32_t> order;
     {
         std::vector<int> sph;
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int i = 0; i < n; ++i) {
-            if (geom[i].shape != kSphere) {
-                order.push_back(i);
-            } else {
+            if (geom[i].shape == kSphere) {
                 sph.push_back(i);
                 const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
                 for (int k = 0; k < 3; ++k) {
@@ -570,8 +568,6 @@ int upload_scene(pt_scene* s) {
                 }
             }
         }
-        while (order.size() % kGroupBodies) order.push_back(-1);
-        const int plane_groups = (int)order.size() / kGroupBodies;
         auto morton = [&](int i) {
             const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
             uint64_t code = 0;
@@ -590,7 +586,7 @@ int upload_scene(pt_scene* s) {
         for (int i : sph) keyed.push_back({morton(i), i});
         std::sort(keyed.begin(), keyed.end());
         for (auto& kv : keyed) order.push_back(kv.second);
-        while (order.size() % (2 * kGroupBodies)) order.push_back(-1);  // an even number of groups
+        while (order.empty() || order.size() % (2 * kGroupBodies)) order.push_back(-1);  // an even number of groups
         const int n_groups = (int)order.size() / kGroupBodies;
         std::vector<DScreen2> members(order.size() / 2), bounds(n_groups / 2);
         for (size_t k = 0; k < order.size(); ++k) {
@@ -618,9 +614,7 @@ int upload_scene(pt_scene* s) {
             }
             float fc[3] = {0.0f, 0.0f, 0.0f};
             float fr2 = -INFINITY;  // empty group: never entered
-            if (g < plane_groups && cnt > 0) {
-                fr2 = INFINITY;
-            } else if (cnt > 0) {
+            if (cnt > 0) {
                 for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
                 double R = 0.0;  // measured from the float centre actually stored
                 for (int k = 0; k < kGroupBodies; ++k) {
