@@ -48,6 +48,7 @@ struct ProfScope {
 
 constexpr int kMaxDepth = 5;  // trace() returns at n > 4: main.cpp:368
 constexpr int kGroupBodies = 8;  // member slots per group of the grouped scan
+constexpr int kSuperGroups = 8;  // groups per super-group
 constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
 enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4 };  // 2..4: device-only, normal = +-e_k
@@ -191,6 +192,7 @@ struct DScene {
     // Grouped layout of the LDS-tiled scan: n_groups groups of kGroupBodies member slots
     // (n_groups is even); bounds and members are float (centre, r^2) records, two per DScreen2;
     // grp_order[slot] is the body index of a member slot (-1: padding).
+    const DScreen2* grp_supers;  // bounds of kSuperGroups consecutive groups (n_groups is a multiple of 2 kSuperGroups)
     const DScreen2* grp_bounds;
     const DScreen2* grp_members;
     const int32_t* grp_order;

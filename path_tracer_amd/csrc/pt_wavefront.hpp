@@ -93,7 +93,8 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 // The spheres are arranged in spatially compact groups of kGroupBodies (built at upload, along a
 // Morton curve).  The float screening records of a tile of groups (group bounds and member
 // spheres, 16 B each) are staged once per block through LDS.  Per pair of groups a wave runs the
-// packed bounding-sphere screen (broadcast LDS reads); only the groups some lane's ray might enter
+// packed bounding-sphere screen (broadcast LDS reads), first on super-groups of kSuperGroups
+// groups, then on the groups of those it might reach; only the groups some lane's ray might enter
 // have their members screened, four per step; a lane whose screen of a member is inconclusive
 // notes the member's slot in a four-entry list of its own, and whenever some lane's list is full
 // every lane evaluates its noted members in FP64 from the full records (per-lane loads).  So the
@@ -106,6 +107,7 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 // Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
 constexpr int kTileGroups = 1024 / kGroupBodies;  // bounds + 1024 members, 16 B each: <= 18 KiB of LDS per block
 struct TileLds {
+    DScreen2 supers[kTileGroups / kSuperGroups / 2];
     DScreen2 bounds[kTileGroups / 2];
     DScreen2 members[kTileGroups * kGroupBodies / 2];
 };
@@ -151,9 +153,12 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     pd.n = 0u;
     const int n_groups = S.n_groups;
     for (int base = 0; base < n_groups; base += kTileGroups) {
-        const int cnt = min(kTileGroups, n_groups - base);  // even
+        const int cnt = min(kTileGroups, n_groups - base);  // a multiple of 2 kSuperGroups
         __syncthreads();  // the previous tile has been consumed by every wave
         {
+            const uint4* ssrc = reinterpret_cast<const uint4*>(S.grp_supers + base / kSuperGroups / 2);
+            uint4* sdst = reinterpret_cast<uint4*>(tile->supers);
+            for (int k = threadIdx.x; k < cnt / kSuperGroups; k += blockDim.x) sdst[k] = ssrc[k];
             const uint4* bsrc = reinterpret_cast<const uint4*>(S.grp_bounds + base / 2);
             uint4* bdst = reinterpret_cast<uint4*>(tile->bounds);
             for (int k = threadIdx.x; k < cnt; k += blockDim.x) bdst[k] = bsrc[k];  // 16 B per lane, coalesced
@@ -163,32 +168,41 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
         }
         __syncthreads();
         if (active) {
-            for (int gp = 0; gp < cnt / 2; ++gp) {
-                lanemask enter[2];
-                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tile->bounds[gp], enter[0], enter[1]);
-                if (((enter[0] | enter[1] | long_dir)) == 0) continue;
+            for (int sp = 0; sp < cnt / kSuperGroups / 2; ++sp) {
+                lanemask reach[2];
+                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tile->supers[sp], reach[0], reach[1]);
+                if (((reach[0] | reach[1] | long_dir)) == 0) continue;
 #pragma unroll 1
-                for (int side = 0; side < 2; ++side) {
-                    if ((enter[side] | long_dir) == 0) continue;
-                    const int g = 2 * gp + side;
+                for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
+                    const int sside = gq / (kSuperGroups / 2);
+                    if ((reach[sside] | long_dir) == 0) continue;
+                    const int gp = sp * kSuperGroups + gq;
+                    lanemask enter[2];
+                    group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tile->bounds[gp], enter[0], enter[1]);
+                    if (((enter[0] | enter[1] | long_dir)) == 0) continue;
 #pragma unroll 1
-                    for (int q = 0; q < kGroupBodies / 4; ++q) {
-                        const DScreen2 sa = tile->members[g * (kGroupBodies / 2) + 2 * q];  // LDS broadcast
-                        const DScreen2 sb = tile->members[g * (kGroupBodies / 2) + 2 * q + 1];
-                        lanemask need[4];
-                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
-                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
-                        if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
+                    for (int side = 0; side < 2; ++side) {
+                        if ((enter[side] | long_dir) == 0) continue;
+                        const int g = 2 * gp + side;
+#pragma unroll 1
+                        for (int q = 0; q < kGroupBodies / 4; ++q) {
+                            const DScreen2 sa = tile->members[g * (kGroupBodies / 2) + 2 * q];  // LDS broadcast
+                            const DScreen2 sb = tile->members[g * (kGroupBodies / 2) + 2 * q + 1];
+                            lanemask need[4];
+                            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
+                            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
+                            if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
 #pragma unroll
-                        for (int h = 0; h < 4; ++h) {
-                            if (need[h] == 0) continue;
-                            const uint32_t slot = (uint32_t)((base + g) * kGroupBodies + 4 * q + h);
-                            // the lanes of need[h] append `slot` to their lists
+                            for (int h = 0; h < 4; ++h) {
+                                if (need[h] == 0) continue;
+                                const uint32_t slot = (uint32_t)((base + g) * kGroupBodies + 4 * q + h);
+                                // the lanes of need[h] append `slot` to their lists
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j)
-                                pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
-                            pd.n += sel32(need[h], 1u, 0u);
-                            if (PTD_MASK(pd.n == 4u) != 0) pending_eval(S, pd, o, d, skip, hit, mint);
+                                for (uint32_t j = 0; j < 4; ++j)
+                                    pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
+                                pd.n += sel32(need[h], 1u, 0u);
+                                if (PTD_MASK(pd.n == 4u) != 0) pending_eval(S, pd, o, d, skip, hit, mint);
+                            }
                         }
                     }
                 }

@@ -374,7 +374,7 @@ struct pt_scene {
     Partition part;
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
-    DevBuf d_grp_members, d_grp_bounds, d_grp_order;
+    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_order;
     DevBuf d_scan_planes, d_scan_spheres, d_scan_screen;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
@@ -586,7 +586,8 @@ int upload_scene(pt_scene* s) {
         for (int i : sph) keyed.push_back({morton(i), i});
         std::sort(keyed.begin(), keyed.end());
         for (auto& kv : keyed) order.push_back(kv.second);
-        while (order.empty() || order.size() % (2 * kGroupBodies)) order.push_back(-1);  // an even number of groups
+        // whole pairs of super-groups (kSuperGroups groups each)
+        while (order.empty() || order.size() % (2 * kSuperGroups * kGroupBodies)) order.push_back(-1);
         const int n_groups = (int)order.size() / kGroupBodies;
         std::vector<DScreen2> members(order.size() / 2), bounds(n_groups / 2);
         for (size_t k = 0; k < order.size(); ++k) {
@@ -633,7 +634,48 @@ int upload_scene(pt_scene* s) {
             r.cz[g & 1] = fc[2];
             r.r2[g & 1] = fr2;
         }
+        // second level: a bounding sphere around the bounds of kSuperGroups consecutive groups
+        const int n_super = n_groups / kSuperGroups;
+        std::vector<DScreen2> supers(n_super / 2);
+        for (int sg = 0; sg < n_super; ++sg) {
+            double c[3] = {0.0, 0.0, 0.0};
+            int cnt = 0;
+            for (int k = 0; k < kSuperGroups; ++k) {
+                const int g = sg * kSuperGroups + k;
+                const DScreen2& b = bounds[g / 2];
+                if (!(b.r2[g & 1] >= 0.0f)) continue;  // empty group
+                c[0] += b.cx[g & 1];
+                c[1] += b.cy[g & 1];
+                c[2] += b.cz[g & 1];
+                cnt++;
+            }
+            float fc[3] = {0.0f, 0.0f, 0.0f};
+            float fr2 = -INFINITY;
+            if (cnt > 0) {
+                for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
+                double R = 0.0;
+                for (int k = 0; k < kSuperGroups; ++k) {
+                    const int g = sg * kSuperGroups + k;
+                    const DScreen2& b = bounds[g / 2];
+                    if (!(b.r2[g & 1] >= 0.0f)) continue;
+                    const double dx = (double)b.cx[g & 1] - fc[0], dy = (double)b.cy[g & 1] - fc[1], dz = (double)b.cz[g & 1] - fc[2];
+                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)b.r2[g & 1]));
+                }
+                fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
+                if (!(fr2 >= 0.0f)) fr2 = INFINITY;
+                c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
+                if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+            }
+            DScreen2& r = supers[sg / 2];
+            r.cx[sg & 1] = fc[0];
+            r.cy[sg & 1] = fc[1];
+            r.cz[sg & 1] = fc[2];
+            r.r2[sg & 1] = fr2;
+        }
         int rcg;
+        if ((rcg = s->d_grp_supers.ensure(sizeof(DScreen2) * supers.size()))) return rcg;
+        HIP_TRY(hipMemcpy(s->d_grp_supers.p, supers.data(), sizeof(DScreen2) * supers.size(), hipMemcpyHostToDevice));
+        D.grp_supers = (const DScreen2*)s->d_grp_supers.p;
         if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
         if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
         if ((rcg = s->d_grp_order.ensure(sizeof(int32_t) * order.size()))) return rcg;
@@ -866,6 +908,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_mat.release();
     s->d_grp_members.release();
     s->d_grp_bounds.release();
+    s->d_grp_supers.release();
     s->d_grp_order.release();
     s->d_scan_planes.release();
     s->d_scan_spheres.release();
