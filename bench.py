@@ -212,6 +212,10 @@ def main():
             }
             if world > 1:
                 out["roofline"]["note"] = "rank 0's kernel launches; per-GPU rate"
+            if wavefront:
+                out["roofline"]["note"] = ("brute-force-equivalent rate: every body test of the reference's scans is "
+                                           "priced in FP64, while the grouped scan proves most of them misses with "
+                                           "bounding-sphere and FP32 screens, so this is not what the FP64 units execute")
             if world == 1 and not args.no_cpu:
                 cb = cpu_baseline(W, H, args.cpu_seconds)
                 out["cpu_baseline"] = cb
