@@ -422,3 +422,19 @@ def test_custom_scene_golden_frames(case):
         r.set_pipeline(pt.PIPELINE_WAVEFRONT)
         assert same_bits(r.render(case["first"], case["n_it"]), z[case["key"] + "_frame"])
     r.close()
+
+
+@pytest.mark.parametrize("keep", [(6, 7, 8, 9, 10, 11, 12, 13), (0, 1, 2, 3, 4, 5, 14), (6, 10, 14), (10, 14)],
+                         ids=["planes_only", "spheres_only", "floor_top_light", "two_lights"])
+def test_degenerate_body_lists_in_both_pipelines(port, keep):
+    """Scenes without spheres, without planes, and with next to nothing: the list, slab and group
+    builders must cope with empty lists, and both pipelines must still agree with the oracle."""
+    W, H = 40, 24
+    drop = tuple(i for i in range(15) if i not in keep)
+    r = pt.Renderer(open_scene("nee15", W, H, 21, drop=drop))
+    s = oracle_scene(port, r, W, H, 21)
+    want, _ = port.render(s, MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    assert same_bits(r.render(0, 3), want)
+    r.close()
