@@ -413,8 +413,9 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
     size_t b = ((size_t)1 << 24) / per_it;
     s->batch = (int)std::min<size_t>(64, std::max<size_t>(1, b));
-    // the wavefront pipeline keeps ~300 B of state per path in HBM: about 2^21 paths per batch
-    size_t wb = ((size_t)1 << 21) / per_it;
+    // the wavefront pipeline keeps ~320 B of state per path in HBM (5.3 GB at 2^24 paths); large
+    // batches also put more rays into every cell of the ray sort
+    size_t wb = ((size_t)1 << 24) / per_it;
     s->wf_batch = (int)std::min<size_t>((size_t)s->batch, std::max<size_t>(1, wb));
     return PT_OK;
 }
