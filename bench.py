@@ -39,12 +39,16 @@ def cpu_baseline(width, height, seconds_target):
 
     cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
     paths_per_it = width * height
-    est_rate = 0.3e6 * cores  # paths/s, to size the sample
+    est_rate = 0.6e6 * cores  # paths/s (the reference does about 0.6-0.7 M paths/s per core), to size the sample
     iters = max(1, int(seconds_target * est_rate / (paths_per_it * cores)))
+    one_core = None
     if _oracle.Ref.available():
         ref = _oracle.Ref()
         secs, _ = ref.time_iterate(1, width, height, iters, cores, seed=1)
         kind = "reference"
+        one_it = max(1, iters // 4)
+        secs1, _ = ref.time_iterate(1, width, height, one_it, 1, seed=1)
+        one_core = float(paths_per_it) * one_it / secs1
     else:
         import ctypes
 
@@ -71,6 +75,7 @@ def cpu_baseline(width, height, seconds_target):
         "unit": "paths/s",
         "cores": cores,
         "kind": kind,
+        "one_core_value": one_core,
         "sample": f"next_event 15-body scene {width}x{height}, {iters} iteration(s) on each of {cores} "
                   f"independent single-thread workers ({paths:.3g} paths, {secs:.1f} s)",
     }

@@ -166,7 +166,7 @@ int pt_save_ppm(const double* buffer, int samples, int width, int height, const 
 /* The reference's hard-coded scenes as data: "nee15" (next_event.cpp:605-689), "main32"
  * (main.cpp:473-607), "pt15" (main.cpp's estimator on the 15-body scene), "nee15_lit" (nee15 with light
  * colour 1 so the direct term is non-zero), "nee15_measured" (nee15_lit with bodies 0,1,6,7 measured),
- * "bipath23" (next_event's estimator on the 23-body, 10-light scene of bipath2.cpp:605-725) and
+ * "nee32" (next_event's estimator on the 32-body scene), "bipath23" (next_event's estimator on the 23-body, 10-light scene of bipath2.cpp:605-725) and
  * "synthetic10k" / "synthetic1k" (nee15 room + 9985 / 985 extra spheres).  Fills desc (desc->bodies = bodies). */
 int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc, pt_body* bodies, int cap);
 

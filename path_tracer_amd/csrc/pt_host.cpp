@@ -257,6 +257,9 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
             Builder::set3(bodies[10].color, 1.0, 1.0, 1.0);
             Builder::set3(bodies[14].color, 1.0, 1.0, 1.0);
         }
+    } else if (s == "nee32") {  // next_event's estimator on the 32-body scene (bidirectional.cpp:755-760 lists the same bodies)
+        desc->estimator = PT_EST_NEE;
+        scene_main32(B);
     } else if (s == "bipath23") {  // next_event's estimator on bipath2.cpp's 23-body scene
         desc->estimator = PT_EST_NEE;
         scene_bipath23(B);

@@ -26,6 +26,7 @@ from _scenes import open_scene, scene_with_extra_planes  # noqa: E402
 CASES = [
     # key, reference program (0 main.cpp, 1 next_event.cpp), scene, W, H, first iteration, iterations, seed
     ("bipath23", 1, lambda W, H: pt.preset("bipath23", W, H), 36, 20, 2, 3, 5),
+    ("nee32", 1, lambda W, H: pt.preset("nee32", W, H), 28, 20, 0, 3, 6),
     ("nee15_extra_planes", 1, lambda W, H: scene_with_extra_planes("nee15", W, H, 1), 30, 18, 0, 3, 9),
     ("main32_extra_planes", 0, lambda W, H: scene_with_extra_planes("main32", W, H, 1), 30, 18, 1, 2, 9),
     ("nee15_open", 1, lambda W, H: open_scene("nee15", W, H, 1, drop=(7, 11, 12, 13)), 24, 16, 0, 3, 17),

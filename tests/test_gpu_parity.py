@@ -12,7 +12,7 @@ from conftest import GOLDEN, same_bits
 from _scenes import open_scene, scene_with_extra_planes
 
 pytestmark = pytest.mark.gpu
-EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE, "bipath23": EST_NEE}
+EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE, "bipath23": EST_NEE, "nee32": EST_NEE}
 
 
 def oracle_scene(port, renderer, W, H, seed, flags=0, tables=None):
@@ -87,7 +87,7 @@ def test_frame_layout(port, W, H, seed):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["nee15", "main32", "pt15", "nee15_lit", "bipath23"])
+@pytest.mark.parametrize("name", ["nee15", "main32", "pt15", "nee15_lit", "bipath23", "nee32"])
 def test_paths_match_oracle(port, name):
     rng = np.random.default_rng(11)
     n = 20000
@@ -121,7 +121,7 @@ def test_golden_frames(port):
 
 
 @pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40),
-                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4), ("bipath23", 72, 40, 4)])
+                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4), ("bipath23", 72, 40, 4), ("nee32", 50, 30, 4)])
 def test_frames_match_oracle(port, name, W, H, n_it):
     r = pt.Renderer(pt.preset(name, W, H, seed=2025))
     s = oracle_scene(port, r, W, H, 2025)
