@@ -218,6 +218,8 @@ def main():
             if world > 1:
                 out["roofline"]["note"] = "rank 0's kernel launches; per-GPU rate"
             if wavefront:
+                out["roofline"]["frac"] = None
+                out["roofline"]["frac_of_no_fma_ceiling"] = None
                 out["roofline"]["note"] = ("brute-force-equivalent rate: every body test of the reference's scans is "
                                            "priced in FP64, while the grouped scan proves most of them misses with "
                                            "bounding-sphere and FP32 screens, so this is not what the FP64 units execute")

@@ -12,5 +12,5 @@ timeout -k 10 200 python3 bench.py --no-cpu --scene main32 > $out/bench_main32.j
 timeout -k 10 200 python3 bench.py --no-cpu --scene nee15_lit --iterations 720 > $out/bench_nee15_lit.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scene nee15_measured --iterations 720 > $out/bench_nee15_measured.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --width 3840 --height 2160 --iterations 256 > $out/bench_nee15_4k.json 2>> $out/bench.err || exit 1
-timeout -k 10 300 python3 bench.py --no-cpu --scene synthetic10k --iterations 2 --steps 2 > $out/bench_synthetic10k.json 2>> $out/bench.err || exit 1
+timeout -k 10 300 python3 bench.py --no-cpu --scene synthetic10k --iterations 63 --steps 1 > $out/bench_synthetic10k.json 2>> $out/bench.err || exit 1
 ls $out $out/trace
