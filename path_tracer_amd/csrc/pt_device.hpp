@@ -76,6 +76,14 @@ PTD_INLINE double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // normalize = divs(sqrt(dot)) = muls(1.0L / s) (main.cpp:92-102): the reciprocal is formed in
 // x87 extended precision and narrowed to the double parameter of muls.
 PTD_INLINE V3 normalize(V3 a) { return muls(a, ptx::x87_recip(sqrt(dot(a, a)))); }
+PTD_INLINE bool same_point(V3 a, V3 b) { return (a.x == b.x) & (a.y == b.y) & (a.z == b.z); }
+// The only NaN the estimator can produce from finite scenes is the flux of a lit vertex that
+// coincides with the previous one (see nee_vertex); flux is an fabs(), so the reference's pixel
+// holds the quiet NaN with the sign clear, which then propagates unchanged.  Samples are stored
+// with exactly that pattern so that accumulators match the reference bit for bit there too.
+PTD_INLINE double flux_nan() { return __longlong_as_double((long long)0x7FF8000000000000ULL); }
+PTD_INLINE double canonical_nan(double v) { return v != v ? flux_nan() : v; }
+PTD_INLINE V3 canonical_nan(V3 v) { return mk(canonical_nan(v.x), canonical_nan(v.y), canonical_nan(v.z)); }
 
 // ---- random numbers --------------------------------------------------------------------
 // Stream contract: xoshiro128+ state seeded from (seed, iteration, domain, index) by three
@@ -222,6 +230,7 @@ struct DScene {
     int32_t estimator;
     uint32_t flags;
     int32_t nee_emission_only;  // see trace_path_nee_compact
+    int32_t flux_finite;        // geometry and colours are finite and moderate: see nee_vertex
     uint64_t seed;
     // Camera (main.cpp:144-152): xd = topright - topleft, yd = bottomleft - topleft
     double cam_o[3], cam_tl[3], cam_xd[3], cam_yd[3];
@@ -746,8 +755,15 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
     V3 scale;
     const V3 lterm = light_term(S, light);
     const bool direct_is_zero = (lterm.x == 0.0) & (lterm.y == 0.0) & (lterm.z == 0.0);
-    // flux is finite for diffuse and chrome, and for glass with ior >= 1
-    if (ELIDE && direct_is_zero && m.material != kMeasured && (m.material != kGlass || m.ior >= 1.0)) {
+    // The term (Le*Lc)*flux is a zero of known sign when Le*Lc is exactly zero and flux is finite:
+    // true for diffuse and chrome, and for glass with ior >= 1, in a scene of finite, moderate
+    // coordinates — unless a chrome or glass vertex coincides with the previous one (a ray that
+    // re-hits the surface it left at t ~ 1e-21): then the reference reflects about a normalised
+    // zero vector, flux is NaN and so is the pixel.  That case takes the full path below.  (The
+    // diffuse bounce only compares against that vector; its flux stays finite.)
+    const bool twin = (m.material != kDiffuse) & same_point(next_point, P);
+    if (ELIDE && direct_is_zero && S.flux_finite && !twin && m.material != kMeasured &&
+        (m.material != kGlass || m.ior >= 1.0)) {
         scale = muls(lterm, 0.0);
         return add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
     }
@@ -826,10 +842,11 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 
 // NEE sample for scenes whose direct term is dead for every light and every material
 // (DScene::nee_emission_only: emission*colour of each light is exactly zero, no measured material,
-// every glass ior >= 1, all colours and emissions finite).  The pixel value is then the recurrence
+// every glass ior >= 1, finite moderate geometry and colours).  The pixel value is then the recurrence
 // L = L*c + e over the lit vertices, deepest first, starting from 0: vertices deeper than the
 // deepest emitting one leave L at zero whether they are lit or not, so their shadow scans are not
-// needed.  The remaining (lane, vertex) shadow tasks of a wave are dealt to its 64 lanes, 64 at a
+// needed.  (One exception is kept: a lit vertex that coincides with the one before it makes the
+// reference's pixel NaN, see nee_vertex; such "twin" vertices count like emitting ones.)  The remaining (lane, vertex) shadow tasks of a wave are dealt to its 64 lanes, 64 at a
 // time: an owner publishes (lane, vertex, light) in a 16-bit LDS slot at the task's rank, lane q
 // takes slot q, reads the vertex from the owner's LDS records, runs the shadow scan, and the
 // owners pick their visibility bits out of the ballot.  Every lane of the wave must call this
@@ -838,18 +855,23 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, double x, double y, const Records& rec,
                                      uint16_t* __restrict__ wave_slots) {
     int n = 0, need = 0, light = 0;
+    unsigned twin = 0;  // bit k: chrome or glass vertex k coincides with the vertex before it (the camera-plane point for k = 0)
     if (valid) {
         V3 o = ld3(S.cam_o);
-        V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157
+        V3 prev = cam_point(S, x, y);
+        V3 d = normalize(sub(prev, o));  // Camera::getRay main.cpp:154-157
 #pragma unroll 1
         for (; n < kMaxDepth; ++n) {
             double mint;
             int hit = nearest_hit(S, o, d, -1, mint);
             if (hit < 0) break;
             const DMat& m = S.mat[hit];
-            V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);
+            V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);  // o = point on return
             rec.put(n, point, hit);
-            if (m.emits) need = n + 1;
+            const bool tw = (m.material != kDiffuse) & same_point(point, prev);
+            twin |= (tw ? 1u : 0u) << n;
+            if (m.emits | tw) need = n + 1;  // a lit twin vertex turns the pixel into NaN: its visibility matters
+            prev = point;
         }
         light = pick_light(S, dr);
     }
@@ -915,7 +937,9 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
         for (int g = need - 1; g >= 0; --g) {
             if (!((vis >> g) & 1u)) continue;
             const DMat& m = S.mat[rec.body(g)];
-            L = add(mul(add(L, scale), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));  // next_event.cpp:452-462
+            // a twin vertex: the reference normalises a zero vector here, flux and L become NaN
+            const V3 sc = ((twin >> g) & 1u) ? mk(flux_nan(), flux_nan(), flux_nan()) : scale;
+            L = add(mul(add(L, sc), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));  // next_event.cpp:452-462
         }
     }
     return L;

@@ -405,8 +405,10 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int 
             dr.rng = load_rng(W, p);
             dr.count = 0;
             const DMat& m = S.mat[hit];
+            // the vertex before this one: the ray origin, or the camera-plane point for the first
+            const V3 prev = depth > 0 ? o : cam_point(S, W.xy[p], W.xy[W.cap + p]);
             V3 point = shade_hit(S.geom[hit], m, dr, o, d, W.t[p]);
-            if (m.emits) W.need[p] = depth + 1;
+            if (m.emits | ((m.material != kDiffuse) & same_point(point, prev))) W.need[p] = depth + 1;  // see trace_path_nee_compact
             store3(W.pts, W.cap, p, depth * 3, point);
             W.bod[(size_t)depth * W.cap + p] = hit;
             W.nrec[p] = depth + 1;
@@ -494,6 +496,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_finish(DScene S, WfState W, dou
     }
     const size_t b = p / J, j = p % J;
     double* out = samples + b * 3 * J + j;
+    L = canonical_nan(L);
     out[0] = L.x;
     out[J] = L.y;
     out[2 * J] = L.z;

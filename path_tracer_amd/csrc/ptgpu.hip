@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(kBlock, MEASURED ? 4 : 5) k_trace(DScene S, Pa
     __syncthreads();
     if (tid < kProfWaves * kProfN) atomicAdd(&g_prof[tid % kProfN], (unsigned long long)s_prof[tid]);
 #endif
+    rgb = canonical_nan(rgb);
     out[0] = rgb.x;
     out[sample_stride] = rgb.y;
     out[2 * sample_stride] = rgb.z;
@@ -281,9 +282,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_paths(DScene S, const int32_t*
     rec.tid = threadIdx.x;
     PathResult R = trace_path<EST, MEASURED, false>(S, dr, xy[2 * i], xy[2 * i + 1], rec);
     if (rgb) {
-        rgb[3 * i] = R.rgb.x;
-        rgb[3 * i + 1] = R.rgb.y;
-        rgb[3 * i + 2] = R.rgb.z;
+        const V3 c = canonical_nan(R.rgb);
+        rgb[3 * i] = c.x;
+        rgb[3 * i + 1] = c.y;
+        rgb[3 * i + 2] = c.z;
     }
     if (nrec) nrec[i] = R.nrec;
     for (int k = 0; k < kMaxDepth; ++k) {
@@ -729,10 +731,22 @@ int upload_scene(pt_scene* s) {
     // The direct term of next-event estimation is dead for the whole scene when emission*colour of
     // every light is exactly zero and the flux it would be scaled by is finite for every material
     // (no measured tables, glass ior >= 1, finite colours); light indices must fit 7 bits.
-    bool dead = s->estimator == PT_EST_NEE && s->lights.size() >= 2;
+    // flux of the direct term can only be finite-by-construction in a scene of finite, moderate numbers
+    bool moderate = true;
+    for (int i = 0; i < n; ++i) {
+        const pt_body& b = s->bodies[i];
+        auto ok = [](double v) { return std::isfinite(v) && std::fabs(v) < 1e100; };
+        for (int k = 0; k < 3; ++k)
+            moderate = moderate && ok(b.color[k]) && ok(b.emission[k]) && ok(b.center[k]) && ok(b.normal[k]);
+        moderate = moderate && ok(b.radius);
+    }
+    for (int k = 0; k < 3; ++k)
+        moderate = moderate && std::isfinite(s->camera.origin[k]) && std::isfinite(s->camera.topleft[k]) &&
+                   std::isfinite(s->camera.topright[k]) && std::isfinite(s->camera.bottomleft[k]);
+    D.flux_finite = moderate ? 1 : 0;
+    bool dead = s->estimator == PT_EST_NEE && s->lights.size() >= 2 && moderate;
     for (int i = 0; i < n && dead; ++i) {
         const pt_body& b = s->bodies[i];
-        for (int k = 0; k < 3; ++k) dead = dead && std::isfinite(b.color[k]) && std::isfinite(b.emission[k]);
         if (b.material == PT_MEASURED) dead = false;
         if (b.material == PT_GLASS && !(b.ior >= 1.0)) dead = false;
     }

@@ -438,3 +438,90 @@ def test_degenerate_body_lists_in_both_pipelines(port, keep):
     r.set_pipeline(pt.PIPELINE_WAVEFRONT)
     assert same_bits(r.render(0, 3), want)
     r.close()
+
+
+def random_scene(seed, W, H):
+    """A seeded random scene: axis-aligned and oblique planes, spheres of mixed sizes, all four
+    combinations of material and emission, lights with and without colour (so that both the
+    live and the dead direct term occur), either estimator."""
+    rng = np.random.default_rng(1000 + seed)
+    d = pt.preset("nee15", W, H, seed=seed)
+    d.estimator = int(rng.integers(0, 2))
+    n_planes = int(rng.integers(0, 9))
+    n_spheres = int(rng.integers(0 if n_planes else 1, 40))
+    n = n_planes + n_spheres + 2
+    bodies = (pt.Body * n)()
+
+    def material(b, light):
+        kind = int(rng.integers(0, 3))
+        b.material = kind
+        for c in range(3):
+            b.color[c] = float(rng.uniform(0.1, 0.95))
+            b.emission[c] = 0.0
+        if kind == pt.GLASS:
+            b.ior = float(rng.uniform(0.8, 1.8))
+            b.reflection = float(rng.uniform(0.0, 0.5))
+        b.brdf_id = -1
+        if light:
+            for c in range(3):
+                b.emission[c] = float(rng.uniform(1.0, 2.0))
+                b.color[c] = 0.0 if light == 1 else float(rng.uniform(0.0, 1.0))
+        elif rng.uniform() < 0.15:  # glows, but below the light threshold
+            for c in range(3):
+                b.emission[c] = float(rng.uniform(0.0, 0.9))
+
+    dark_lights = rng.uniform() < 0.6  # every light with colour 0 -> the direct term is dead scene-wide
+    k = 0
+    for i in range(n_planes):
+        b = bodies[k]
+        b.shape = pt.PLANE
+        if rng.uniform() < 0.65:
+            axis = int(rng.integers(0, 3))
+            sign = 1.0 if rng.uniform() < 0.5 else -1.0
+            c = [0.0, 0.0, 0.0]
+            c[axis] = -sign * float(rng.uniform(0.6, 4.0)) + (2.0 if axis == 1 else 0.0)
+            nrm = [0.0, 0.0, 0.0]
+            nrm[axis] = sign
+        else:
+            nrm = list(rng.normal(size=3))
+            c = list(rng.uniform(-3, 3, size=3) + np.array([0.0, 2.0, 0.0]))
+        for q in range(3):
+            b.center[q] = float(c[q])
+            b.normal[q] = float(nrm[q])
+        material(b, 0)
+        k += 1
+    for i in range(n_spheres + 2):
+        b = bodies[k]
+        b.shape = pt.SPHERE
+        c = rng.uniform([-1.8, 0.6, -0.5], [1.8, 4.4, 2.4])
+        for q in range(3):
+            b.center[q] = float(c[q])
+        b.radius = float(rng.choice([0.05, 0.1, 0.3, 0.6])) * float(rng.uniform(0.7, 1.3))
+        light = 0
+        if i >= n_spheres or rng.uniform() < 0.1:
+            light = 1 if dark_lights else 2
+        material(b, light)
+        k += 1
+    d.bodies = bodies
+    d.body_count = n
+    d._keep = bodies
+    return d
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scenes_match_oracle(port, seed):
+    W, H = 32, 20
+    r = pt.Renderer(random_scene(seed, W, H))
+    s = oracle_scene(port, r, W, H, seed)
+    want, _ = port.render(s, MODE_PIXEL, 1, 2)
+    assert same_bits(r.render(1, 2), want)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    assert same_bits(r.render(1, 2), want)
+    rng = np.random.default_rng(seed)
+    rays = edge_rays(rng, 4000)
+    bodies, nb = r.bodies()
+    for skip in (-1, nb - 1, nb // 2):
+        idx, t = r.intersect_batch(rays, skip=skip)
+        _, idx0, t0 = port.intersect(s, rays, skip=skip)
+        assert np.array_equal(idx, idx0) and same_bits(t, t0)
+    r.close()
