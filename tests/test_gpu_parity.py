@@ -440,7 +440,7 @@ def test_degenerate_body_lists_in_both_pipelines(port, keep):
     r.close()
 
 
-def random_scene(seed, W, H):
+def random_scene(seed, W, H, max_spheres=40):
     """A seeded random scene: axis-aligned and oblique planes, spheres of mixed sizes, all four
     combinations of material and emission, lights with and without colour (so that both the
     live and the dead direct term occur), either estimator."""
@@ -448,7 +448,7 @@ def random_scene(seed, W, H):
     d = pt.preset("nee15", W, H, seed=seed)
     d.estimator = int(rng.integers(0, 2))
     n_planes = int(rng.integers(0, 9))
-    n_spheres = int(rng.integers(0 if n_planes else 1, 40))
+    n_spheres = int(rng.integers(0 if n_planes else 1, max_spheres))
     n = n_planes + n_spheres + 2
     bodies = (pt.Body * n)()
 
