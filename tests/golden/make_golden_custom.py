@@ -52,6 +52,21 @@ def main():
     with open(os.path.join(HERE, "frames_custom.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
+    # save() on values a converged render does not contain: NaN, infinities, negatives, huge and
+    # tiny numbers, exact boundaries of the truncation to int
+    ref = Ref()
+    W, H, samples = 6, 3, 3
+    vals = [float("nan"), float("inf"), -float("inf"), -0.0, -1e-300, -0.5, -7.0, 1e300, 3.0 * 2147483647.0 / 255.0,
+            3.0 * 2147483648.0 / 255.0, 3.0 * 256.0 / 255.0, 3.0 * 255.999999 / 255.0, 3.0, 2.9999999999999996,
+            3.0000000000000004, 1e-320, 0.011764705882352941 * 3.0, 0.5]
+    buf = np.resize(np.array(vals, dtype=np.float64), (H, W, 3))
+    ppm = {}
+    for prog in (0, 1):
+        data, fname = ref.save(prog, buf, samples, W, H)
+        ppm[str(prog)] = dict(name=fname, text=data.decode())
+    with open(os.path.join(HERE, "save_edge.json"), "w") as f:
+        json.dump(dict(W=W, H=H, samples=samples, values_hex=[float(v).hex() for v in buf.reshape(-1)], ppm=ppm), f)
+
 
 if __name__ == "__main__":
     main()

@@ -74,3 +74,15 @@ def test_no_cpu_fallback_when_gpu_missing():
         pytest.skip("a GPU is present")
     with pytest.raises(pt.PtError):
         pt.Renderer(pt.preset("nee15", 8, 8))
+
+
+def test_save_ppm_edge_values(tmp_path):
+    """NaN, infinities, negatives and the int-truncation boundaries, as the reference's save() prints them."""
+    with open(os.path.join(GOLDEN, "save_edge.json")) as f:
+        g = json.load(f)
+    buf = np.array([float.fromhex(h) for h in g["values_hex"]]).reshape(g["H"], g["W"], 3)
+    path = str(tmp_path / "edge.ppm")
+    pt.save_ppm(buf, g["samples"], path)
+    with open(path, "rb") as f:
+        data = f.read().decode()
+    assert data == g["ppm"]["0"]["text"] == g["ppm"]["1"]["text"]

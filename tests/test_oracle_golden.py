@@ -128,3 +128,10 @@ def test_custom_scene_frames_match_reference(port, golden_scene, case):
     got, draws = port.render(s, MODE_PIXEL, case["first"], case["n_it"])
     assert same_bits(got, z[case["key"] + "_frame"])
     assert draws == case["draws"]
+
+
+def test_save_edge_values(port):
+    with open(os.path.join(GOLDEN, "save_edge.json")) as f:
+        g = json.load(f)
+    buf = np.array([float.fromhex(h) for h in g["values_hex"]]).reshape(g["H"], g["W"], 3)
+    assert port.save_ppm(buf, g["samples"], g["W"], g["H"]).decode() == g["ppm"]["1"]["text"]
