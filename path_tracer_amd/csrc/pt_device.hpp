@@ -166,8 +166,15 @@ struct DGeom {  // 64 bytes, what the nearest-hit scan reads
         };
     };
     int32_t shape;
-    int32_t pad[3];
+    int32_t pad[3];  // scan lists: pad[0] = body index; pad[1..2] = a double, see origin0_term
 };
+// Scan-list records carry the part of the test that depends only on the ray origin, evaluated
+// for the origin (0,0,0) where the shadow rays of the reference start (next_event.cpp:167,406-407):
+// plane: n.(c - 0) = nx*cx + ny*cy + nz*cz;  sphere: |0 - c|^2 - r^2.  Same operations in the same
+// order as the scan would perform them, so using the stored value changes no bit.
+PTD_INLINE double origin0_term(const DGeom& g) {
+    return __hiloint2double(g.pad[2], g.pad[1]);
+}
 
 // Per-ray data of the single-precision sphere screen (see make_rayf).
 struct RayF {
@@ -212,6 +219,7 @@ struct DScene {
     const DGeom* scan_planes;
     const DGeom* scan_spheres;
     const DScreen2* scan_screen;
+    const DScreen2* scan_screen0;  // the same pairs with |c|^2 - r^2 in place of r^2: the screen from the origin (0,0,0)
     int32_t n_planes, n_spheres;
     // Slab of axis k (bit k of slab_mask): the two axis-aligned planes of that axis with the
     // smallest and the largest coordinate, bodies slab_ilo[k] and slab_ihi[k].  slab_big[k] bounds
@@ -401,16 +409,13 @@ PTD_INLINE void scan_slab(double lo, double hi, double big, int ilo, int ihi, do
         merge_masked(valid, t2, (int)sel32(pick_lo, (uint32_t)ihi, (uint32_t)ilo), skip, hit, mint);
     }
 }
-PTD_INLINE void merge_sphere(const DGeom& g, V3 o, V3 d, int skip, int& hit, double& mint) {
-    PT_PROF(kProfScanExact);
-    double t;
-    bool ok = scan_sphere_exact(g, o, d, t);
-    merge_hit(ok, t, g.pad[0], skip, hit, mint);
-}
-// Steps 1 and 2 of the scan: the planes outside the slabs, then the slabs.
+// Steps 1 and 2 of the scan: the planes outside the slabs, then the slabs.  ORIGIN0: the ray starts
+// at exactly (0,0,0) — `o` must be that — and the origin-dependent terms come from the records.
+template <bool ORIGIN0>
 PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ planes, V3 o, V3 d, int skip, int& hit,
                                 double& mint) {
     PT_PROF(kProfScanPlanes);
+    if (ORIGIN0) o = mk(0.0, 0.0, 0.0);  // c - 0.0 folds to c
     const int n_planes = S.n_planes;
     for (int k = 0; k < n_planes; ++k) {
         const DGeom g = planes[k];
@@ -420,7 +425,15 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
             case kPlaneX: ok = scan_plane_axis(g.cx, o.x, d.x, t); break;
             case kPlaneY: ok = scan_plane_axis(g.cy, o.y, d.y, t); break;
             case kPlaneZ: ok = scan_plane_axis(g.cz, o.z, d.z, t); break;
-            default: ok = scan_plane(g, o, d, t); break;
+            default:
+                if (ORIGIN0) {
+                    const double n_dot_u = g.nx * d.x + g.ny * d.y + g.nz * d.z;
+                    t = origin0_term(g) / n_dot_u;
+                    ok = !((n_dot_u > -0.00001) && (n_dot_u < 0.00001));
+                } else {
+                    ok = scan_plane(g, o, d, t);
+                }
+                break;
         }
         const int i = g.pad[0];
         bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
@@ -434,30 +447,70 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
     if (S.slab_mask & 4)
         scan_slab(S.slab_lo[2], S.slab_hi[2], S.slab_big[2], S.slab_ilo[2], S.slab_ihi[2], o.z, d.z, skip, hit, mint);
 }
+// Sphere::intersect from the origin (0,0,0): D = -c, c-term stored in the record.
+PTD_INLINE bool scan_sphere_exact_origin0(const DGeom& g, V3 d, double& t) {
+    t = 0.0;
+    const double dx = 0.0 - g.cx, dy = 0.0 - g.cy, dz = 0.0 - g.cz;
+    const double b = dx * d.x + dy * d.y + dz * d.z;
+    const double disc = (b * b) - origin0_term(g);
+    const bool ok = (disc > 0.0) && (b < 0.0);
+    if (__builtin_amdgcn_ballot_w64(ok) != 0) {
+        double dd = disc;
+        asm volatile("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
+        t = -b - sqrt(dd);
+    }
+    return ok;
+}
+// The sphere screen from the origin (0,0,0): the record holds the centre and, in place of r^2,
+// the float c-term |c|^2 - r^2.  Same error bounds as sphere_possible2_masks.
+PTD_INLINE void sphere_possible2_masks_origin0(float dx, float dy, float dz, float e_disc, float e_b, const DScreen2& sc,
+                                               lanemask& m0, lanemask& m1) {
+    f32x2 bf = -__builtin_elementwise_fma(sc.cz, (f32x2)(dz), __builtin_elementwise_fma(sc.cy, (f32x2)(dy), sc.cx * dx));
+    f32x2 discf = __builtin_elementwise_fma(bf, bf, -sc.r2);
+    m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
+    m1 = PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b));
+}
+template <bool ORIGIN0>
 PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ planes, const DGeom* __restrict__ spheres,
                                  const DScreen2* __restrict__ screen, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    scan_all_planes(S, planes, o, d, skip, hit, mint);
+    scan_all_planes<ORIGIN0>(S, planes, o, d, skip, hit, mint);
     const int n_spheres = S.n_spheres;
     if (n_spheres > 0) {
         PT_PROF(kProfScanScreen);
-        const RayF rf = make_rayf(o, d, S.sphere_c1max, S.sphere_r2max);
+        const RayF rf = make_rayf(ORIGIN0 ? mk(0.0, 0.0, 0.0) : o, d, S.sphere_c1max, S.sphere_r2max);
         const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
         const float e_disc = rf.e_disc, e_b = rf.e_b;
         for (int k = 0; 2 * k < n_spheres; ++k) {
             const DScreen2 sc = screen[k];
             lanemask m0, m1;
-            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
-            if (m0 != 0) merge_sphere(spheres[2 * k], o, d, skip, hit, mint);
-            if (m1 != 0) merge_sphere(spheres[2 * k + 1], o, d, skip, hit, mint);
+            if (ORIGIN0)
+                sphere_possible2_masks_origin0(fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
+            else
+                sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((h ? m1 : m0) == 0) continue;
+                PT_PROF(kProfScanExact);
+                const DGeom g = spheres[2 * k + h];
+                double t;
+                const bool ok = ORIGIN0 ? scan_sphere_exact_origin0(g, d, t) : scan_sphere_exact(g, o, d, t);
+                merge_hit(ok, t, g.pad[0], skip, hit, mint);
+            }
         }
     }
     tmin = mint;
     return hit;
 }
 PTD_INLINE int nearest_hit(const DScene& S, V3 o, V3 d, int skip, double& tmin) {
-    return nearest_hit_lists(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, skip, tmin);
+    return nearest_hit_lists<false>(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, skip, tmin);
+}
+// The scan of a shadow ray towards `d` with `light` left out (next_event.cpp:405-426).  Unless the
+// scene asks for the lights' real centres every shadow ray starts at (0,0,0).
+PTD_INLINE int nearest_hit_shadow(const DScene& S, V3 lc, V3 d, int light, double& tmin) {
+    if (S.flags & 1u) return nearest_hit_lists<false>(S, S.scan_planes, S.scan_spheres, S.scan_screen, lc, d, light, tmin);
+    return nearest_hit_lists<true>(S, S.scan_planes, S.scan_spheres, S.scan_screen0, lc, d, light, tmin);
 }
 
 // ---- materials -------------------------------------------------------------------------
@@ -828,7 +881,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
             bd = normalize(sub(P, lc));
         }
         double mint;
-        int hit = nearest_hit(S, lc, bd, light, mint);
+        int hit = nearest_hit_shadow(S, lc, bd, light, mint);
         if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
         PT_PROF(kProfNeeVertex);
@@ -915,7 +968,7 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
                 bd = normalize(sub(P, lc));  // next_event.cpp:405-407
             }
             double mint;
-            int hit = nearest_hit(S, lc, bd, lt, mint);
+            int hit = nearest_hit_shadow(S, lc, bd, lt, mint);
             lit = hit == rec.body_of(g, owner);  // next_event.cpp:428-430
         }
         const lanemask lit_mask = PTD_MASK(lit);

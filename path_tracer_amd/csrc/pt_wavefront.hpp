@@ -147,7 +147,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     const lanemask long_dir = PTD_MASK(!(fdx * fdx + fdy * fdy + fdz * fdz <= 1.000001f));
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    if (active) scan_all_planes(S, S.scan_planes, o, d, skip, hit, mint);
+    if (active) scan_all_planes<false>(S, S.scan_planes, o, d, skip, hit, mint);
     Pending pd;
     pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
     pd.n = 0u;

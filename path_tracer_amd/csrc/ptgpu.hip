@@ -377,7 +377,7 @@ struct pt_scene {
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
     DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_order;
-    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen;
+    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
     DevBuf d_xs[2], d_ys[2], d_rowstart[2], d_npix[2], d_samples[2], d_accum;
@@ -543,13 +543,32 @@ int upload_scene(pt_scene* s) {
         g.pad[0] = -1;
         scan_spheres.push_back(g);
     }
-    std::vector<DScreen2> scan_screen(scan_spheres.size() / 2);
+    // the origin-dependent term of every record for the origin (0,0,0) (see origin0_term)
+    auto put_term = [](DGeom& g, double v) {
+        uint64_t u;
+        memcpy(&u, &v, 8);
+        g.pad[1] = (int32_t)(uint32_t)u;
+        g.pad[2] = (int32_t)(uint32_t)(u >> 32);
+    };
+    for (DGeom& g : scan_planes) put_term(g, g.nx * (g.cx - 0.0) + g.ny * (g.cy - 0.0) + g.nz * (g.cz - 0.0));
+    for (DGeom& g : scan_spheres) {
+        const double dx = 0.0 - g.cx, dy = 0.0 - g.cy, dz = 0.0 - g.cz;
+        put_term(g, (dx * dx + dy * dy + dz * dz) - g.nx);
+    }
+    std::vector<DScreen2> scan_screen(scan_spheres.size() / 2), scan_screen0(scan_spheres.size() / 2);
     for (size_t k = 0; k < scan_spheres.size(); ++k) {
+        const DGeom& g = scan_spheres[k];
         DScreen2& r = scan_screen[k / 2];
-        r.cx[k & 1] = scan_spheres[k].fcx;
-        r.cy[k & 1] = scan_spheres[k].fcy;
-        r.cz[k & 1] = scan_spheres[k].fcz;
-        r.r2[k & 1] = scan_spheres[k].fr2;
+        r.cx[k & 1] = g.fcx;
+        r.cy[k & 1] = g.fcy;
+        r.cz[k & 1] = g.fcz;
+        r.r2[k & 1] = g.fr2;
+        DScreen2& r0 = scan_screen0[k / 2];
+        r0.cx[k & 1] = g.fcx;
+        r0.cy[k & 1] = g.fcy;
+        r0.cz[k & 1] = g.fcz;
+        // float c-term of the float centre, one rounding (the screen's error bound allows several)
+        r0.r2[k & 1] = (float)(((double)g.fcx * g.fcx + (double)g.fcy * g.fcy + (double)g.fcz * g.fcz) - (double)g.fr2);
     }
     // Grouped layout of the LDS-tiled scan (wavefront pipeline): the spheres in groups of
     // kGroupBodies, ordered along a Morton curve so that a group is spatially compact.  Per group a
@@ -698,13 +717,16 @@ int upload_scene(pt_scene* s) {
     if (scan_planes.empty()) scan_planes.resize(1);
     if (scan_spheres.empty()) scan_spheres.resize(2);
     if (scan_screen.empty()) scan_screen.resize(1);
+    if (scan_screen0.empty()) scan_screen0.resize(1);
     int rc;
     if ((rc = s->d_scan_planes.ensure(sizeof(DGeom) * scan_planes.size()))) return rc;
     if ((rc = s->d_scan_spheres.ensure(sizeof(DGeom) * scan_spheres.size()))) return rc;
     if ((rc = s->d_scan_screen.ensure(sizeof(DScreen2) * scan_screen.size()))) return rc;
+    if ((rc = s->d_scan_screen0.ensure(sizeof(DScreen2) * scan_screen0.size()))) return rc;
     HIP_TRY(hipMemcpy(s->d_scan_planes.p, scan_planes.data(), sizeof(DGeom) * scan_planes.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_scan_spheres.p, scan_spheres.data(), sizeof(DGeom) * scan_spheres.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_scan_screen.p, scan_screen.data(), sizeof(DScreen2) * scan_screen.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_scan_screen0.p, scan_screen0.data(), sizeof(DScreen2) * scan_screen0.size(), hipMemcpyHostToDevice));
     if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
     if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
     if ((rc = s->d_lights.ensure(sizeof(int32_t) * std::max<size_t>(1, s->lights.size())))) return rc;
@@ -718,6 +740,7 @@ int upload_scene(pt_scene* s) {
     D.scan_planes = (const DGeom*)s->d_scan_planes.p;
     D.scan_spheres = (const DGeom*)s->d_scan_spheres.p;
     D.scan_screen = (const DScreen2*)s->d_scan_screen.p;
+    D.scan_screen0 = (const DScreen2*)s->d_scan_screen0.p;
     D.n_planes = n_planes;
     D.n_spheres = n_spheres;
     D.n_bodies = n;
@@ -928,6 +951,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_scan_planes.release();
     s->d_scan_spheres.release();
     s->d_scan_screen.release();
+    s->d_scan_screen0.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
     for (int k = 0; k < 2; ++k) {
