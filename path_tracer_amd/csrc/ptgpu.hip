@@ -2,7 +2,7 @@
 //
 // Render pipeline for one batch of B iterations:
 //   k_frame_layout : per iteration, the jitter tables of Renderer::iterate (main.cpp:352-357):
-//                    y per row, x at every 32nd pixel of a row (running sums, exactly as the
+//                    y per row, x at every 8th pixel of a row (running sums, exactly as the
 //                    reference's loops accumulate them; k_trace continues the sum from the nearest
 //                    checkpoint), row lengths and the running-index row starts.
 //   k_trace<EST>   : one thread per (destination pixel, iteration): camera ray, <=5 segments of
@@ -44,7 +44,7 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 constexpr int kBlock = 256;
-constexpr int kXStride = 32;  // the x running sum of a row is stored at every 32nd column
+constexpr int kXStride = 8;  // the x running sum of a row is stored at every 8th column
 
 struct Partition {
     int rank, world;
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kBlock, MEASURED ? 4 : 5) k_trace(DScene S, Pa
         while (slot >= rs[r + 1]) r++;
         int c = slot - rs[r];
         // x of column c: the row's running sum x += xstep (main.cpp:355-357), continued from the
-        // stored value at the previous multiple of 32
+        // stored value at the previous multiple of 8
         const int CK = (W + kXStride - 1) / kXStride;
         x = xs[((size_t)b * H + r) * CK + c / kXStride];
         for (int i = c & (kXStride - 1); i > 0; --i) x += xstep;
