@@ -1059,7 +1059,11 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     auto launch_layout = [&](int k) -> int {
         const int q = k & 1;
         const int B = std::min(batch, n_iterations - k * batch);
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_trace[q], 0));  // batch k-2 has read these tables
+        if (k >= 2) {
+            // batch k-2 has read these tables: its estimator kernel and its accumulation (npix)
+            HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_trace[q], 0));
+            HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_acc[q], 0));
+        }
         hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, s->st_layout, s->seed, W, H,
                            first_iteration + k * batch, s->xstep, s->ystep, (double*)s->d_xs[q].p, (double*)s->d_ys[q].p,
                            (int32_t*)s->d_rowstart[q].p, (int32_t*)s->d_npix[q].p);

@@ -30,7 +30,13 @@ def all_reduce_accumulator(accum, group=None):
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal on one GPU shared by several ranks: stage through host memory
+            host = accum.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            accum.copy_(host)
+        else:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
     return accum
 
 
