@@ -40,5 +40,9 @@ if rank == 0:
         print("  values", got[y, x], want[y, x], "ratio", got[y, x] / want[y, x])
         owner = ptdist.tile_owner(W, H, world)
         print("  owners of mismatching pixels", np.unique(owner[ys, xs], return_counts=True))
-dist.barrier()
+    status = torch.tensor([1 if len(bad) else 0])
+else:
+    status = torch.tensor([0])
+dist.all_reduce(status)
 dist.destroy_process_group()
+sys.exit(int(status.item()))

@@ -525,3 +525,35 @@ def test_random_scenes_match_oracle(port, seed):
         _, idx0, t0 = port.intersect(s, rays, skip=skip)
         assert np.array_equal(idx, idx0) and same_bits(t, t0)
     r.close()
+
+
+def test_two_ranks_share_one_gpu():
+    """Two ranks (gloo, both on cuda:0) render their tile partitions concurrently and all-reduce; the
+    reduced frame equals the single-partition frame bit for bit.  Concurrent processes stretch the gaps
+    between the layout, estimator and accumulation streams, which is what exposes table-reuse races."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "scripts", "rehearse_ranks.py"), "60"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "mismatching entries 0 " in out.stdout
+
+
+def test_overlapped_batches_equal_one_call_per_iteration():
+    """One call over many batches (layout, estimator and accumulation overlap on three streams and
+    reuse two table sets) gives the same bits as one call per iteration, where nothing is reused."""
+    import torch
+    W, H, IT = 1024, 768, 1200
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=1))
+    stream = torch.cuda.current_stream().cuda_stream
+    whole = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    r.render_device(0, IT, whole.data_ptr(), stream)
+    single = torch.zeros_like(whole)
+    for k in range(IT):
+        r.render_device(k, 1, single.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(whole.view(torch.int64), single.view(torch.int64))
