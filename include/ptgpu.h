@@ -125,7 +125,10 @@ int pt_set_pipeline(pt_scene* scene, int pipeline);
 int pt_render(pt_scene* scene, int first_iteration, int n_iterations, double* accum_host);
 
 /* Same, with `accum_dev` in device memory and work queued on `stream` (a hipStream_t, or NULL).
- * Returns without synchronising. */
+ * Returns without synchronising; when the work queued on `stream` has completed, so has the render
+ * (the library's two internal side streams are joined back into `stream`).  A scene owns one set of
+ * work buffers: queue successive renders of one scene on the same stream, or synchronise between
+ * them; renders of different scenes are independent. */
 int pt_render_device(pt_scene* scene, int first_iteration, int n_iterations, double* accum_dev, void* stream);
 
 /* Nearest-hit scan (main.cpp:372-383) over a ray batch: rays6[n][6] = origin, direction.

@@ -363,6 +363,20 @@ struct DevBuf {
     }
 };
 
+// Device allocation local to one diagnostic call: freed on every return path.
+template <class T>
+struct Tmp {
+    T* p = nullptr;
+    Tmp() = default;
+    Tmp(const Tmp&) = delete;
+    Tmp& operator=(const Tmp&) = delete;
+    ~Tmp() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, sizeof(T) * std::max<size_t>(n, 1)); }
+    operator T*() const { return p; }
+};
+
 }  // namespace
 
 struct pt_scene {
@@ -1150,19 +1164,16 @@ int pt_intersect_batch(pt_scene* s, const double* rays6, int n, int skip, int32_
     if (!s || !rays6 || !idx || !t || n < 0) return fail(PT_ERR_INVALID, "pt_intersect_batch: bad argument");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    double *d_r = nullptr, *d_t = nullptr;
-    int32_t* d_i = nullptr;
-    HIP_TRY(hipMalloc(&d_r, sizeof(double) * 6 * n));
-    HIP_TRY(hipMalloc(&d_t, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&d_i, sizeof(int32_t) * n));
+    Tmp<double> d_r, d_t;
+    Tmp<int32_t> d_i;
+    HIP_TRY(d_r.alloc((size_t)6 * n));
+    HIP_TRY(d_t.alloc((size_t)n));
+    HIP_TRY(d_i.alloc((size_t)n));
     HIP_TRY(hipMemcpy(d_r, rays6, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_intersect_batch, dim3((n + 255) / 256), dim3(256), 0, 0, s->ds, d_r, n, skip, d_i, d_t);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(idx, d_i, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(t, d_t, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_r);
-    (void)hipFree(d_t);
-    (void)hipFree(d_i);
     return PT_OK;
 }
 
@@ -1171,15 +1182,13 @@ int pt_intersect_all(pt_scene* s, const double* rays6, int n, double* t_all) {
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(s->device));
     const size_t nb = s->bodies.size();
-    double *d_r = nullptr, *d_t = nullptr;
-    HIP_TRY(hipMalloc(&d_r, sizeof(double) * 6 * n));
-    HIP_TRY(hipMalloc(&d_t, sizeof(double) * n * nb));
+    Tmp<double> d_r, d_t;
+    HIP_TRY(d_r.alloc((size_t)6 * n));
+    HIP_TRY(d_t.alloc((size_t)n * nb));
     HIP_TRY(hipMemcpy(d_r, rays6, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_intersect_all, dim3((n + 255) / 256), dim3(256), 0, 0, s->ds, d_r, n, d_t);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(t_all, d_t, sizeof(double) * n * nb, hipMemcpyDeviceToHost));
-    (void)hipFree(d_r);
-    (void)hipFree(d_t);
     return PT_OK;
 }
 
@@ -1190,16 +1199,16 @@ int pt_trace_paths(pt_scene* s, const int32_t* it_idx2, const double* xy, int n,
     HIP_TRY(hipSetDevice(s->device));
     int rc = check_measured_tables(s);
     if (rc) return rc;
-    int32_t *d_ii = nullptr, *d_nrec = nullptr, *d_bod = nullptr, *d_vis = nullptr, *d_used = nullptr;
-    double *d_xy = nullptr, *d_rgb = nullptr, *d_pts = nullptr;
-    HIP_TRY(hipMalloc(&d_ii, sizeof(int32_t) * 2 * n));
-    HIP_TRY(hipMalloc(&d_xy, sizeof(double) * 2 * n));
-    HIP_TRY(hipMalloc(&d_rgb, sizeof(double) * 3 * n));
-    HIP_TRY(hipMalloc(&d_nrec, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&d_bod, sizeof(int32_t) * 5 * n));
-    HIP_TRY(hipMalloc(&d_pts, sizeof(double) * 15 * n));
-    HIP_TRY(hipMalloc(&d_vis, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&d_used, sizeof(int32_t) * n));
+    Tmp<int32_t> d_ii, d_nrec, d_bod, d_vis, d_used;
+    Tmp<double> d_xy, d_rgb, d_pts;
+    HIP_TRY(d_ii.alloc((size_t)2 * n));
+    HIP_TRY(d_xy.alloc((size_t)2 * n));
+    HIP_TRY(d_rgb.alloc((size_t)3 * n));
+    HIP_TRY(d_nrec.alloc((size_t)n));
+    HIP_TRY(d_bod.alloc((size_t)5 * n));
+    HIP_TRY(d_pts.alloc((size_t)15 * n));
+    HIP_TRY(d_vis.alloc((size_t)n));
+    HIP_TRY(d_used.alloc((size_t)n));
     HIP_TRY(hipMemcpy(d_ii, it_idx2, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_xy, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     dim3 grid((n + kBlock - 1) / kBlock);
@@ -1219,20 +1228,13 @@ int pt_trace_paths(pt_scene* s, const int32_t* it_idx2, const double* xy, int n,
     if (points) HIP_TRY(hipMemcpy(points, d_pts, sizeof(double) * 15 * n, hipMemcpyDeviceToHost));
     if (visible) HIP_TRY(hipMemcpy(visible, d_vis, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     if (used) HIP_TRY(hipMemcpy(used, d_used, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_ii);
-    (void)hipFree(d_xy);
-    (void)hipFree(d_rgb);
-    (void)hipFree(d_nrec);
-    (void)hipFree(d_bod);
-    (void)hipFree(d_pts);
-    (void)hipFree(d_vis);
-    (void)hipFree(d_used);
     return PT_OK;
 }
 
 int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t* row_len, int32_t* nrows) {
     if (!s || !ys || !xs || !row_len || !nrows) return fail(PT_ERR_INVALID, "pt_frame_layout: null argument");
     HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());  // table set 0 is shared with renders that may still be in flight
     int rc = ensure_render_buffers(s);
     if (rc) return rc;
     const int W = s->width, H = s->height;
@@ -1265,16 +1267,14 @@ int pt_rng_fill(uint64_t seed, uint32_t iteration, uint32_t domain, uint32_t ind
     if (n < 0 || !k || !u) return fail(PT_ERR_INVALID, "pt_rng_fill: bad argument");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(g_device));
-    int32_t* d_k = nullptr;
-    double* d_u = nullptr;
-    HIP_TRY(hipMalloc(&d_k, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&d_u, sizeof(double) * n));
+    Tmp<int32_t> d_k;
+    Tmp<double> d_u;
+    HIP_TRY(d_k.alloc((size_t)n));
+    HIP_TRY(d_u.alloc((size_t)n));
     hipLaunchKernelGGL(k_rng_fill, dim3(1), dim3(64), 0, 0, seed, iteration, domain, index, n, d_k, d_u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(k, d_k, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(u, d_u, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_k);
-    (void)hipFree(d_u);
     return PT_OK;
 }
 
@@ -1286,18 +1286,15 @@ int pt_x87_eval(int kind, int on_device, const double* a, const double* b, int n
     }
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(g_device));
-    double *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
-    HIP_TRY(hipMalloc(&d_a, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&d_b, sizeof(double) * n));
-    HIP_TRY(hipMalloc(&d_o, sizeof(double) * n));
+    Tmp<double> d_a, d_b, d_o;
+    HIP_TRY(d_a.alloc((size_t)n));
+    HIP_TRY(d_b.alloc((size_t)n));
+    HIP_TRY(d_o.alloc((size_t)n));
     HIP_TRY(hipMemcpy(d_a, a, sizeof(double) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_b, b, sizeof(double) * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_x87_eval, dim3((n + 255) / 256), dim3(256), 0, 0, kind, d_a, d_b, n, d_o);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_a);
-    (void)hipFree(d_b);
-    (void)hipFree(d_o);
     return PT_OK;
 }
 
@@ -1306,20 +1303,17 @@ int pt_brdf_lookup(pt_scene* s, int id, const double* angles4, int n, double* rg
     if (id < 0 || id >= PT_MAX_BRDF || !s->d_brdf[id].p) return fail(PT_ERR_INVALID, "pt_brdf_lookup: table not uploaded");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    double *d_a = nullptr, *d_rgb = nullptr;
-    int32_t* d_ind = nullptr;
-    HIP_TRY(hipMalloc(&d_a, sizeof(double) * 4 * n));
-    HIP_TRY(hipMalloc(&d_rgb, sizeof(double) * 3 * n));
-    HIP_TRY(hipMalloc(&d_ind, sizeof(int32_t) * n));
+    Tmp<double> d_a, d_rgb;
+    Tmp<int32_t> d_ind;
+    HIP_TRY(d_a.alloc((size_t)4 * n));
+    HIP_TRY(d_rgb.alloc((size_t)3 * n));
+    HIP_TRY(d_ind.alloc((size_t)n));
     HIP_TRY(hipMemcpy(d_a, angles4, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_brdf_lookup, dim3((n + 255) / 256), dim3(256), 0, 0, (const double*)s->d_brdf[id].p, d_a, n, d_rgb,
                        d_ind);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ind, d_ind, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_a);
-    (void)hipFree(d_rgb);
-    (void)hipFree(d_ind);
     return PT_OK;
 }
 

@@ -121,7 +121,9 @@ def test_golden_frames(port):
 
 
 @pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40),
-                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4), ("bipath23", 72, 40, 4), ("nee32", 50, 30, 4)])
+                                           ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4), ("bipath23", 72, 40, 4), ("nee32", 50, 30, 4),
+                                           # the headline frame size, a few iterations of it
+                                           ("nee15", 1024, 768, 3), ("main32", 1024, 768, 3)])
 def test_frames_match_oracle(port, name, W, H, n_it):
     r = pt.Renderer(pt.preset(name, W, H, seed=2025))
     s = oracle_scene(port, r, W, H, 2025)
