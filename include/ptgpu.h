@@ -163,6 +163,14 @@ int pt_x87_eval(int kind, int on_device, const double* a, const double* b, int n
  * theta_in, phi_in, theta_out, phi_out -> rgb[n][3], ind[n] (table index). */
 int pt_brdf_lookup(pt_scene* scene, int brdf_id, const double* angles4, int n, double* rgb, int32_t* ind);
 
+/* The lookup as the estimator makes it for a lit vertex of a measured body: vec6[n][6] = incoming
+ * direction, outgoing direction; each goes through vector_to_spherical (raytrace3.cpp:725-728) and
+ * the four angles through lookup_brdf_val (MatusikBRDF.h:50-80), the composition sketched in
+ * raytrace3.cpp:646-676.  The device computes the table index from the vectors without
+ * trigonometric calls; it equals the index of pt_brdf_lookup on the angles except within a few ulps
+ * of a bin edge.  The scene must contain a PT_MEASURED body. */
+int pt_brdf_lookup_vectors(pt_scene* scene, int brdf_id, const double* vec6, int n, double* rgb, int32_t* ind);
+
 /* Replaces save() (main.cpp:408-434 / next_event.cpp:533-554): ASCII P3, byte-compatible. */
 int pt_save_ppm(const double* buffer, int samples, int width, int height, const char* path);
 

@@ -232,6 +232,14 @@ class Renderer:
         _check(lib().pt_brdf_lookup(self._h, brdf_id, _p(angles4), n, _p(rgb), _p(ind)))
         return rgb, ind
 
+    def brdf_lookup_vectors(self, brdf_id, vec6):
+        vec6 = np.ascontiguousarray(vec6, dtype=np.float64)
+        n = vec6.shape[0]
+        rgb = np.zeros((n, 3))
+        ind = np.zeros(n, dtype=np.int32)
+        _check(lib().pt_brdf_lookup_vectors(self._h, brdf_id, _p(vec6), n, _p(rgb), _p(ind)))
+        return rgb, ind
+
     def intersect_batch(self, rays6, skip=-1):
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64)
         n = rays6.shape[0]

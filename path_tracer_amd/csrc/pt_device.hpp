@@ -230,6 +230,7 @@ struct DScene {
     const DMat* mat;
     const int32_t* lights;  // body indices with any emission channel >= 1 (next_event.cpp:362-367)
     const double* brdf[8];
+    const double* brdf_bins;  // bin edges of the table indices as thresholds (see brdf_index_of_vectors)
     float sphere_c1max;  // max over spheres of |cx|+|cy|+|cz|   (error bound of the float screen)
     float sphere_r2max;  // max over spheres of radius^2
     int32_t n_bodies;
@@ -668,16 +669,22 @@ PTD_INLINE int brdf_index(double theta_in, double fi_in, double theta_out, doubl
     return phi_diff_index(fi_diff) + theta_diff_index(theta_diff) * 360 / 2 + theta_half_index(theta_half) * 360 / 2 * 90;
 }
 
-// lookup_brdf_val :50-80.  Three 8-byte gathers at strides of 11.66 MB from an HBM-resident table.
+// The values of lookup_brdf_val :68-79 for a table index.  The device copy of a table keeps the
+// red, green and blue value of an index next to each other (24 bytes).
+PTD_INLINE V3 brdf_rgb(const double* __restrict__ table, int ind) {
+    const double* e = table + 3 * (size_t)ind;
+    double r = e[0] * (1.0 / 1500.0);
+    double g = e[1] * (1.15 / 1500.0);
+    double b = e[2] * (1.66 / 1500.0);
+    if (r < 0.0 || g < 0.0 || b < 0.0) r = g = b = 0.0;
+    return mk(r, g, b);
+}
+// lookup_brdf_val :50-80 from the four angles.
 PTD_INLINE V3 brdf_lookup(const double* __restrict__ table, double theta_in, double fi_in, double theta_out,
                           double fi_out, int* ind_out) {
     int ind = brdf_index(theta_in, fi_in, theta_out, fi_out);
     if (ind_out) *ind_out = ind;
-    double r = table[ind] * (1.0 / 1500.0);
-    double g = table[ind + kBrdfN] * (1.15 / 1500.0);
-    double b = table[ind + 2 * kBrdfN] * (1.66 / 1500.0);
-    if (r < 0.0 || g < 0.0 || b < 0.0) r = g = b = 0.0;
-    return mk(r, g, b);
+    return brdf_rgb(table, ind);
 }
 
 // vector_to_spherical raytrace3.cpp:725-728 (pow(x, 2) is x*x)
@@ -788,15 +795,117 @@ PTD_INLINE V3 light_term(const DScene& S, int light) {
     return mul(mk(lm.emr, lm.emg, lm.emb), mk(lm.colr, lm.colg, lm.colb));
 }
 
-// The measured-material term of a lit vertex: both directions to spherical angles, then the table
-// lookup.  Kept out of line: its trigonometric expansions need about 200 vector registers, which
-// inlined would set the register budget (and the occupancy) of the whole estimator kernel; as a
-// call, only the waves that reach a measured vertex pay for it.
-__device__ __attribute__((noinline)) V3 measured_term(const double* __restrict__ table, V3 bd, V3 nprime) {
-    double ti, pi, to, po;
-    vector_to_spherical(bd, ti, pi);
-    vector_to_spherical(nprime, to, po);
-    return brdf_lookup(table, ti, pi, to, po, nullptr);
+// ---- the table index straight from the two direction vectors -------------------------------
+// measured_term's angles come from vectors (vector_to_spherical) and go straight back into sines
+// and cosines (std_coords_to_half_diff_coords), and the half/difference angles are only ever
+// binned.  This form computes the same quantities without a single trigonometric call:
+//   theta = atan(y/x):  cos theta = |x|/h, sin theta = sign(x) y/h,  h = sqrt(x^2 + y^2);
+//   phi = acos(c), c = z/len:  cos phi = c, sin phi = sqrt((1-c)(1+c));
+//   fi_half = atan2(hy, hx):  cos = hx/r, sin = hy/r, r = sqrt(hx^2 + hy^2);  sin(theta_half) = r;
+// and bins theta_half = acos(hz), theta_diff = acos(dz), fi_diff = atan2(dy, dx) by comparing hz, dz
+// and dx/dy with the cosines / cotangents of the bin edges (tables built at upload, descending;
+// uniform binary search).  Each replaced call is accurate to an ulp or two, like the library
+// calls of the reference's libm and of the device's, which already differ from each other in the
+// last place; an index changes only when an angle sits within a few ulps of a bin edge, or on the
+// pole of the parametrisation where fi_diff is rounding noise in every implementation.
+// NaN inputs give index 0 in every term, as the reference's double -> int conversions do.
+constexpr int kBinsHalf = 0, kBinsDiff = 128, kBinsPhi = 256, kBinsTotal = 512;
+
+// Number of edges passed: the largest pos with v <= T[pos] (T[0] counts as passed, T descending,
+// padded with values no v reaches).  NaN passes nothing.
+template <int SIZE>
+PTD_INLINE int bins_passed(const double* __restrict__ T, double v) {
+    int pos = 0;
+#pragma unroll
+    for (int step = SIZE / 2; step > 0; step >>= 1)
+        if (v <= T[pos + step]) pos += step;
+    return pos;
+}
+
+PTD_INLINE void spherical_sincos(V3 v, double& ct, double& st, double& cp, double& sp) {
+    const double h = sqrt(v.x * v.x + v.y * v.y);
+    ct = fabs(v.x) / h;
+    st = __builtin_copysign(1.0, v.x) * v.y / h;
+    double c = v.z / sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (!(fabs(c) <= 1.0)) c = __builtin_nan("");  // acos outside [-1, 1]
+    cp = c;
+    sp = sqrt((1.0 - c) * (1.0 + c));
+}
+
+PTD_INLINE int brdf_index_of_vectors(const double* __restrict__ bins, V3 vin, V3 vout) {
+    double ct_i, st_i, cp_i, sp_i, ct_o, st_o, cp_o, sp_o;
+    spherical_sincos(vin, ct_i, st_i, cp_i, sp_i);
+    spherical_sincos(vout, ct_o, st_o, cp_o, sp_o);
+    // std_coords_to_half_diff_coords :159-205
+    const double in_vec_z = ct_i, in_vec_x = st_i * cp_i, in_vec_y = st_i * sp_i;
+    double in[3] = {in_vec_x, in_vec_y, in_vec_z};
+    brdf_normalize(in);
+    const double out_vec_z = ct_o, out_vec_x = st_o * cp_o, out_vec_y = st_o * sp_o;
+    double half[3] = {(in_vec_x + out_vec_x) / 2.0, (in_vec_y + out_vec_y) / 2.0, (in_vec_z + out_vec_z) / 2.0};
+    brdf_normalize(half);
+    const double r = sqrt(half[0] * half[0] + half[1] * half[1]);  // sin(theta_half)
+    // rotation by -fi_half about (0,0,1); on the pole (r == 0) atan2 gives 0 or pi
+    double cos1 = half[0] / r, sin1 = -half[1] / r;
+    if (r == 0.0) {
+        cos1 = __builtin_copysign(1.0, half[0]);
+        sin1 = 0.0;
+    }
+    const double bi_normal[3] = {0.0, 1.0, 0.0};
+    const double normal[3] = {0.0, 0.0, 1.0};
+    double temp[3], diff[3];
+    {
+        const double* vector = in;
+        const double* axis = normal;
+        temp[0] = vector[0] * cos1;
+        temp[1] = vector[1] * cos1;
+        temp[2] = vector[2] * cos1;
+        double t = axis[0] * vector[0] + axis[1] * vector[1] + axis[2] * vector[2];
+        t = t * (1.0 - cos1);
+        temp[0] += axis[0] * t;
+        temp[1] += axis[1] * t;
+        temp[2] += axis[2] * t;
+        temp[0] += (axis[1] * vector[2] - axis[2] * vector[1]) * sin1;
+        temp[1] += (axis[2] * vector[0] - axis[0] * vector[2]) * sin1;
+        temp[2] += (axis[0] * vector[1] - axis[1] * vector[0]) * sin1;
+    }
+    {
+        // rotation by -theta_half about (0,1,0): cos = half.z, sin = -r
+        const double cos2 = half[2], sin2 = -r;
+        const double* vector = temp;
+        const double* axis = bi_normal;
+        diff[0] = vector[0] * cos2;
+        diff[1] = vector[1] * cos2;
+        diff[2] = vector[2] * cos2;
+        double t = axis[0] * vector[0] + axis[1] * vector[1] + axis[2] * vector[2];
+        t = t * (1.0 - cos2);
+        diff[0] += axis[0] * t;
+        diff[1] += axis[1] * t;
+        diff[2] += axis[2] * t;
+        diff[0] += (axis[1] * vector[2] - axis[2] * vector[1]) * sin2;
+        diff[1] += (axis[2] * vector[0] - axis[0] * vector[2]) * sin2;
+        diff[2] += (axis[0] * vector[1] - axis[1] * vector[0]) * sin2;
+    }
+    // theta_half_index(acos(half.z)) :211-223
+    const int i_half = bins_passed<128>(bins + kBinsHalf, half[2]);
+    // theta_diff_index(acos(diff.z)) :228-237; acos is NaN outside [-1, 1] and NaN indexes bin 0
+    int i_diff = bins_passed<128>(bins + kBinsDiff, diff[2]);
+    if (diff[2] < -1.0) i_diff = 0;
+    // phi_diff_index(atan2(diff.y, diff.x)) :241-257: the angle is taken modulo pi, so it depends on
+    // cot = x/y alone; y == 0 gives 0 or pi, and pi stays pi (bin 179) only for y = +0 with x
+    // negative (or -0), -pi being moved to 0.
+    int i_phi;
+    if (diff[1] == 0.0)
+        i_phi = (!__builtin_signbit(diff[1]) && __builtin_signbit(diff[0]) && !(diff[0] != diff[0])) ? 179 : 0;
+    else
+        i_phi = bins_passed<256>(bins + kBinsPhi, diff[0] / diff[1]);
+    return i_phi + i_diff * 360 / 2 + i_half * 360 / 2 * 90;
+}
+
+// The measured-material term of a lit vertex (the incoming and outgoing directions in the roles
+// vector_to_spherical, raytrace3.cpp:725-728, and lookup_brdf_val, MatusikBRDF.h:50-80, give them).
+PTD_INLINE V3 measured_term(const double* __restrict__ table,
+                                                      const double* __restrict__ bins, V3 bd, V3 nprime) {
+    return brdf_rgb(table, brdf_index_of_vectors(bins, bd, nprime));
 }
 
 // One lit vertex of the NEE loop (next_event.cpp:442-463): L = ((L + (Le*Lc)*flux) * c) + e.
@@ -824,7 +933,7 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
     if (MEASURED && m.material == kMeasured) {
         // Defined by this build: the table RGB replaces the scalar flux (the reference's own
         // lookups, raytrace3.cpp:646-676, are never executed).
-        V3 f = measured_term(S.brdf[m.brdf_id], bd, nprime);
+        V3 f = measured_term(S.brdf[m.brdf_id], S.brdf_bins, bd, nprime);
         scale = mul(lterm, f);
     } else {
         V3 light_brdf = bounce(m, dr, bd, nprime);

@@ -136,12 +136,11 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 // ---- k_trace -----------------------------------------------------------------------------
 // __launch_bounds__(256, 5): five 256-thread blocks per CU (5 waves per SIMD).  Their LDS records
 // (5 x 32 KB) just fit the 160 KiB of a CU and the register file allows 96 VGPRs per lane; the
-// estimator is bound by VALU issue, and the fifth wave buys ~8 %.  The variant with the
-// measured-BRDF lookup calls it out of line (104 registers) and runs at 4.
+// estimator is bound by VALU issue, and the fifth wave buys ~8 %.
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
 // shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, MEASURED ? 4 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
@@ -342,6 +341,19 @@ __global__ void k_brdf_lookup(const double* __restrict__ table, const double* __
     ind[i] = id;
 }
 
+__global__ void k_brdf_lookup_vectors(const double* __restrict__ table, const double* __restrict__ bins,
+                                      const double* __restrict__ vec6, int n, double* __restrict__ rgb,
+                                      int32_t* __restrict__ ind) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 a = ld3(vec6 + 6 * (size_t)i), b = ld3(vec6 + 6 * (size_t)i + 3);
+    ind[i] = brdf_index_of_vectors(bins, a, b);
+    const V3 f = measured_term(table, bins, a, b);
+    rgb[3 * i] = f.x;
+    rgb[3 * i + 1] = f.y;
+    rgb[3 * i + 2] = f.z;
+}
+
 // ---- host state ------------------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;
@@ -391,7 +403,7 @@ struct pt_scene {
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
     DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_order;
-    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0;
+    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
     DevBuf d_xs[2], d_ys[2], d_rowstart[2], d_npix[2], d_samples[2], d_accum;
@@ -757,6 +769,22 @@ int upload_scene(pt_scene* s) {
     D.scan_screen0 = (const DScreen2*)s->d_scan_screen0.p;
     D.n_planes = n_planes;
     D.n_spheres = n_spheres;
+    if (s->has_measured) {
+        // Bin edges of the table indices (MatusikBRDF.h:211-257) as thresholds, descending:
+        // theta_half bin k starts at (k/90)^2 pi/2 and theta_diff bin k at k pi/180 (cosines),
+        // fi_diff bin k at k pi/180 (cotangents).  Entry 0 is never read; the padding is never reached.
+        std::vector<double> bins(kBinsTotal, -INFINITY);
+        const double half_pi = M_PI / 2.0;
+        for (int k = 1; k < 90; ++k) {
+            bins[kBinsHalf + k] = std::cos(((double)k * k / 8100.0) * half_pi);
+            bins[kBinsDiff + k] = std::cos((double)k * half_pi / 90.0);
+        }
+        for (int k = 1; k < 180; ++k) bins[kBinsPhi + k] = std::cos(k * M_PI / 180.0) / std::sin(k * M_PI / 180.0);
+        int rcb = s->d_brdf_bins.ensure(sizeof(double) * bins.size());
+        if (rcb) return rcb;
+        HIP_TRY(hipMemcpy(s->d_brdf_bins.p, bins.data(), sizeof(double) * bins.size(), hipMemcpyHostToDevice));
+        D.brdf_bins = (const double*)s->d_brdf_bins.p;
+    }
     D.n_bodies = n;
     D.sphere_c1max = c1max * 1.0001f;
     D.sphere_r2max = r2max * 1.0001f;
@@ -966,6 +994,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_scan_spheres.release();
     s->d_scan_screen.release();
     s->d_scan_screen0.release();
+    s->d_brdf_bins.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
     for (int k = 0; k < 2; ++k) {
@@ -1002,7 +1031,16 @@ int pt_brdf_upload(pt_scene* s, int id, const double* table, size_t n) {
     HIP_TRY(hipSetDevice(s->device));
     int rc = s->d_brdf[id].ensure(n * sizeof(double));
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(s->d_brdf[id].p, table, n * sizeof(double), hipMemcpyHostToDevice));
+    // The file keeps three planes (red, green, blue; MatusikBRDF.h:68-72).  On the device the three
+    // values of an index are adjacent, so that a lookup touches one or two 64-byte sectors, not three.
+    std::vector<double> rgb(n);
+    const size_t N = n / 3;
+    for (size_t i = 0; i < N; ++i) {
+        rgb[3 * i] = table[i];
+        rgb[3 * i + 1] = table[N + i];
+        rgb[3 * i + 2] = table[2 * N + i];
+    }
+    HIP_TRY(hipMemcpy(s->d_brdf[id].p, rgb.data(), n * sizeof(double), hipMemcpyHostToDevice));
     s->ds.brdf[id] = (const double*)s->d_brdf[id].p;
     return PT_OK;
 }
@@ -1311,6 +1349,26 @@ int pt_brdf_lookup(pt_scene* s, int id, const double* angles4, int n, double* rg
     HIP_TRY(hipMemcpy(d_a, angles4, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_brdf_lookup, dim3((n + 255) / 256), dim3(256), 0, 0, (const double*)s->d_brdf[id].p, d_a, n, d_rgb,
                        d_ind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ind, d_ind, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_brdf_lookup_vectors(pt_scene* s, int id, const double* vec6, int n, double* rgb, int32_t* ind) {
+    if (!s || !vec6 || !rgb || !ind || n < 0) return fail(PT_ERR_INVALID, "pt_brdf_lookup_vectors: bad argument");
+    if (id < 0 || id >= PT_MAX_BRDF || !s->d_brdf[id].p) return fail(PT_ERR_INVALID, "pt_brdf_lookup_vectors: table not uploaded");
+    if (!s->ds.brdf_bins) return fail(PT_ERR_INVALID, "pt_brdf_lookup_vectors: the scene has no measured body");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    Tmp<double> d_v, d_rgb;
+    Tmp<int32_t> d_ind;
+    HIP_TRY(d_v.alloc((size_t)6 * n));
+    HIP_TRY(d_rgb.alloc((size_t)3 * n));
+    HIP_TRY(d_ind.alloc((size_t)n));
+    HIP_TRY(hipMemcpy(d_v, vec6, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_brdf_lookup_vectors, dim3((n + 255) / 256), dim3(256), 0, 0, (const double*)s->d_brdf[id].p,
+                       s->ds.brdf_bins, (const double*)d_v, n, (double*)d_rgb, (int32_t*)d_ind);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ind, d_ind, sizeof(int32_t) * n, hipMemcpyDeviceToHost));

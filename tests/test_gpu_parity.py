@@ -227,6 +227,46 @@ def test_measured_brdf_lookup_and_render(port):
     r.close()
 
 
+def test_measured_index_from_vectors(port):
+    """The estimator's trigonometry-free table index (from the two direction vectors) against the
+    reference's chain vector_to_spherical -> lookup_brdf_val evaluated with libm on the host."""
+    r = pt.Renderer(pt.preset("nee15_measured", 8, 8, seed=1))
+    index_table = np.concatenate([np.arange(pt.BRDF_TABLE_DOUBLES // 3, dtype=np.float64)] * 3)
+    r.brdf_upload(0, index_table)
+    rng = np.random.default_rng(77)
+    n = 400000
+    v = rng.normal(size=(n, 2, 3))
+    v /= np.linalg.norm(v, axis=2, keepdims=True)
+    # special directions: axes, coordinate planes, equal and opposite pairs, poles of the parametrisation
+    ax = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0.6, 0.8, 0], [0, 0.6, -0.8],
+                   [-0.8, 0, 0.6], [0.0, 0.0, 0.0]], dtype=np.float64)
+    pairs = np.array([[a, b] for a in ax for b in ax])
+    v[: len(pairs)] = pairs
+    v[len(pairs): len(pairs) + 1000, 1] = v[len(pairs): len(pairs) + 1000, 0]            # in == out
+    v[len(pairs) + 1000: len(pairs) + 2000, 1] = -v[len(pairs) + 1000: len(pairs) + 2000, 0]  # opposite
+    v[len(pairs) + 2000: len(pairs) + 3000, :, 0] = 0.0                                   # x == 0
+    v[len(pairs) + 3000: len(pairs) + 4000, :, 1] = 0.0                                   # y == 0
+    a_in = port.vector_to_spherical(v[:, 0])
+    a_out = port.vector_to_spherical(v[:, 1])
+    angles = np.concatenate([a_in, a_out], axis=1)
+    _, want = port.brdf_lookup(index_table, angles)
+    rgb, got = r.brdf_lookup_vectors(0, v.reshape(n, 6))
+    assert np.array_equal(np.rint(rgb[:, 0] * 1500.0).astype(np.int64), got)
+    bad = np.nonzero(got != want)[0]
+    # Generic directions: equal indices (an angle within a few ulps of a bin edge would be the
+    # exception).  Special directions sit exactly on bin edges or on the pole of the half/difference
+    # parametrisation, where fi_diff is rounding noise of whichever sin/cos/atan2 is used.
+    generic = bad[bad >= len(pairs) + 4000]
+    assert len(generic) <= 2, (len(generic), generic[:10])
+    special = bad[bad < len(pairs) + 4000]
+    for i in special:
+        gi, wi = int(got[i]), int(want[i])
+        same_half = gi // (180 * 90) == wi // (180 * 90)
+        near = abs(gi - wi) in (1, 179, 180, 180 * 90) or same_half
+        assert near, (i, v[i], gi, wi)
+    r.close()
+
+
 def test_errors_are_reported_not_fatal():
     d = pt.preset("nee15", 8, 8)
     d.body_count = 0
