@@ -32,6 +32,10 @@
                                       base-class Shape::center == (0,0,0) that
                                       next_event.cpp:167,406-407 actually reads */
 
+#define POR_F_RAYTRACE3 2u /* raytrace3.cpp's variant of main.cpp's trace(): a hit needs
+                              t > 0.0000001L (raytrace3.cpp:776) and the radiance is
+                              color*(trace(next) + V3()) + emission (raytrace3.cpp:805,840) */
+
 typedef struct por_scene {
     int32_t width, height;
     ptor_camera camera;
@@ -135,8 +139,38 @@ static v3 cam_ray_dir(const cam* c, double x, double y) { return normalize(sub(c
 
 /* ---- shapes ------------------------------------------------------------------------- */
 
+/* V3::cross raytrace3.cpp:128-133 */
+static inline v3 cross(v3 a, v3 b) {
+    return V((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+
+/* Rectangle ctor raytrace3.cpp:254-265: normal = normalize((p3-p1) x (p2-p1)). */
+static v3 rect_normal(const double* c) {
+    v3 p1 = ld3(c), p2 = ld3(c + 3), p3 = ld3(c + 6);
+    return normalize(cross(sub(p3, p1), sub(p2, p1)));
+}
+
+/* Rectangle::intersect raytrace3.cpp:283-308 (v1, v3 as the ctor stores them, :264-265). */
+static double intersect_rectangle(const ptor_body* b, v3 o, v3 dir) {
+    v3 p1 = ld3(b->corners), p2 = ld3(b->corners + 3), p3 = ld3(b->corners + 6), p4 = ld3(b->corners + 9);
+    v3 normal = ld3(b->normal);
+    v3 v1 = normalize(sub(p2, p1));
+    v3 v3_ = normalize(sub(p4, p3));
+    double n_dot_u = dot(normal, dir);
+    if ((n_dot_u > -0.00001L) && (n_dot_u < 0.00001L)) return (double)-1.0L;
+    double n_dot_p0 = dot(normal, sub(p1, o));
+    double t = n_dot_p0 / n_dot_u;
+    if (t < 1.0L) return (double)-1.0L;
+    v3 hit = add(o, muls(dir, t));
+    v3 v4 = normalize(sub(hit, p1));
+    v3 v5 = normalize(sub(hit, p3));
+    if ((dot(v1, v4) > 0.0L) && (dot(v3_, v5) > 0.0L)) return t;
+    return (double)-1.0L;
+}
+
 /* Plane::intersect main.cpp:181-191; Sphere::intersect main.cpp:210-222. */
 static double intersect(const ptor_body* b, v3 o, v3 dir) {
+    if (b->shape == PTOR_RECTANGLE) return intersect_rectangle(b, o, dir);
     if (b->shape == PTOR_PLANE) {
         v3 n = ld3(b->normal);
         double n_dot_u = dot(n, dir);
@@ -156,7 +190,7 @@ static double intersect(const ptor_body* b, v3 o, v3 dir) {
 
 /* getNormal: Plane main.cpp:192-194, Sphere main.cpp:224-226. */
 static v3 shape_normal(const ptor_body* b, v3 point) {
-    if (b->shape == PTOR_PLANE) return ld3(b->normal);
+    if (b->shape == PTOR_PLANE || b->shape == PTOR_RECTANGLE) return ld3(b->normal); /* raytrace3.cpp:278-281 */
     return normalize(sub(point, ld3(b->center)));
 }
 
@@ -168,7 +202,8 @@ static int nearest(const por_scene* s, v3 o, v3 dir, int skip, double* t_out) {
     for (int i = 0; i < s->body_count; i++) {
         if (i == skip) continue;
         double t = intersect(&s->bodies[i], o, dir);
-        if ((t > 0) && (t <= mint)) {
+        int positive = (s->flags & POR_F_RAYTRACE3) ? (t > 0.0000001L) : (t > 0);
+        if (positive && (t <= mint)) {
             mint = t;
             hit = i;
         }
@@ -374,6 +409,7 @@ static v3 radiance_pt(const por_scene* s, draws* d, v3 o, v3 dir) {
     v3 L = V(0.0L, 0.0L, 0.0L);
     for (int k = n - 1; k >= 0; k--) {
         const ptor_body* b = &s->bodies[bodies[k]];
+        if (s->flags & POR_F_RAYTRACE3) L = add(L, V(0.0L, 0.0L, 0.0L)); /* + direct_color raytrace3.cpp:840 */
         L = add(mul(L, ld3(b->color)), ld3(b->emission));
     }
     return L;
@@ -556,6 +592,14 @@ void por_get_rays(const por_scene* s, const double* xy, int n, double* rays6) {
 /* Plane ctor normalisation (main.cpp:176-179): stored = normalize(given). */
 void por_plane_normal(const double* in3, double* out3) {
     v3 n = normalize(ld3(in3));
+    out3[0] = n.x;
+    out3[1] = n.y;
+    out3[2] = n.z;
+}
+
+/* Rectangle ctor normal (raytrace3.cpp:260) from the twelve corner coordinates. */
+void por_rect_normal(const double* corners12, double* out3) {
+    v3 n = rect_normal(corners12);
     out3[0] = n.x;
     out3[1] = n.y;
     out3[2] = n.z;

@@ -6,7 +6,7 @@
 #define PTOR_TYPES_H
 #include <stdint.h>
 
-enum { PTOR_SPHERE = 0, PTOR_PLANE = 1 };
+enum { PTOR_SPHERE = 0, PTOR_PLANE = 1, PTOR_RECTANGLE = 2 /* Rectangle(p1,p2,p3,p4) raytrace3.cpp:244-276 */ };
 enum { PTOR_DIFFUSE = 0, PTOR_CHROME = 1, PTOR_GLASS = 2, PTOR_MEASURED = 3 };
 enum { PTOR_EST_PT = 0, PTOR_EST_NEE = 1 };
 
@@ -22,6 +22,7 @@ typedef struct ptor_body {
     double reflection;
     int32_t brdf_id;
     int32_t pad;
+    double corners[12]; /* rectangles: p1, p2, p3, p4 as passed to the ctor */
 } ptor_body;
 
 typedef struct ptor_camera {

@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY — harness around the UNMODIFIED reference sources.
 //
-// The two reference programs are textually included (from where they lie under the
+// The reference programs (main.cpp, next_event.cpp, raytrace3.cpp) are textually included (from where they lie under the
 // reference checkout; nothing is copied) into separate namespaces, with `main` renamed by
 // the preprocessor.  The scene each program builds on the stack of its main()
 // (/root/reference/main.cpp:473-607, next_event.cpp:605-689) is borrowed through the boost
@@ -8,6 +8,7 @@
 // comes from the linker-wrapped rand() in ref_rt.cpp.
 //
 // Build recipe: oracle/Makefile (outputs only under oracle/_ref/).
+#include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -44,6 +45,16 @@ namespace ref_nee {
 #undef main
 }  // namespace ref_nee
 
+// raytrace3.cpp: main.cpp's estimator with a hit threshold of 1e-7 and a third shape, Rectangle
+// (raytrace3.cpp:244-330, :761-851).  It includes MatusikBRDF.h itself, hence the guard reset below.
+// Built with -fno-access-control: Rectangle's corner points are private members.
+namespace ref_rt3 {
+#define main ref_main
+#include PTOR_REF_RT3
+#undef main
+}  // namespace ref_rt3
+
+#undef _MATUSIKBRDFREADER_H_
 namespace ref_brdf {
 #include PTOR_REF_BRDF
 }
@@ -85,6 +96,64 @@ struct NEE {
     static int run_main(int argc, const char** argv) { return ref_nee::ref_main(argc, argv); }
     static void save(V3* b, int s, int w, int h) { ref_nee::save(b, s, w, h); }
 };
+
+struct RT3 {
+    enum { prog = 2 };
+    typedef ref_rt3::V3 V3;
+    typedef ref_rt3::Ray Ray;
+    typedef ref_rt3::Scene Scene;
+    typedef ref_rt3::Renderer Renderer;
+    typedef ref_rt3::Body Body;
+    typedef ref_rt3::Shape Shape;
+    typedef ref_rt3::Plane Plane;
+    typedef ref_rt3::Sphere Sphere;
+    typedef ref_rt3::Rectangle Rectangle;
+    typedef ref_rt3::Material Material;
+    typedef ref_rt3::Chrome Chrome;
+    typedef ref_rt3::Glass Glass;
+    typedef ref_rt3::Camera Camera;
+    static int run_main(int argc, const char** argv) { return ref_rt3::ref_main(argc, argv); }
+    static void save(V3* b, int s, int w, int h) { ref_rt3::save(b, s, w, h); }
+};
+
+// main.cpp / next_event.cpp keep `Body** objects` + body_count, raytrace3.cpp a vector<Body*>
+// (and never sets body_count).
+template <class B>
+int body_count_of(B** const&, int body_count) { return body_count; }
+template <class B>
+int body_count_of(const std::vector<B*>& v, int) { return (int)v.size(); }
+template <class B>
+void set_objects(B**& dst, std::vector<B*>& v) { dst = v.data(); }
+template <class B>
+void set_objects(std::vector<B*>& dst, std::vector<B*>& v) { dst = v; }
+
+// The third shape exists only in raytrace3.cpp.
+template <class T>
+bool describe_rectangle(typename T::Shape*, ptor_body&) { return false; }
+template <>
+bool describe_rectangle<RT3>(RT3::Shape* sh, ptor_body& o) {
+    RT3::Rectangle* r = dynamic_cast<RT3::Rectangle*>(sh);
+    if (!r) return false;
+    o.shape = PTOR_RECTANGLE;
+    const RT3::V3 p[4] = {r->p1, r->p2, r->p3, r->p4};
+    for (int k = 0; k < 4; k++) {
+        o.corners[3 * k] = p[k].x;
+        o.corners[3 * k + 1] = p[k].y;
+        o.corners[3 * k + 2] = p[k].z;
+    }
+    o.normal[0] = r->normal.x;
+    o.normal[1] = r->normal.y;
+    o.normal[2] = r->normal.z;
+    return true;
+}
+template <class T>
+typename T::Shape* make_rectangle(const ptor_body&) { return nullptr; }
+template <>
+RT3::Shape* make_rectangle<RT3>(const ptor_body& b) {
+    const double* c = b.corners;
+    return new RT3::Rectangle(RT3::V3(c[0], c[1], c[2]), RT3::V3(c[3], c[4], c[5]), RT3::V3(c[6], c[7], c[8]),
+                              RT3::V3(c[9], c[10], c[11]));
+}
 
 std::function<void(void*)> g_session;
 std::string g_scratch = "/tmp";
@@ -150,12 +219,12 @@ template <class T>
 int scene_bodies(ptor_body* out, int cap, ptor_camera* cam) {
     int count = 0;
     with_scene<T>([&](typename T::Scene* s) {
-        count = s->body_count;
+        count = body_count_of(s->objects, s->body_count);
         put3(cam->origin, s->camera.origin);
         put3(cam->topleft, s->camera.topleft);
         put3(cam->topright, s->camera.topright);
         put3(cam->bottomleft, s->camera.bottomleft);
-        for (int i = 0; i < s->body_count && i < cap; i++) {
+        for (int i = 0; i < count && i < cap; i++) {
             typename T::Body* b = s->objects[i];
             ptor_body o;
             memset(&o, 0, sizeof o);
@@ -168,7 +237,7 @@ int scene_bodies(ptor_body* out, int cap, ptor_camera* cam) {
                 o.shape = PTOR_SPHERE;
                 put3(o.center, sp->center);
                 o.radius = sp->radius;
-            } else {
+            } else if (!describe_rectangle<T>(b->shape, o)) {
                 o.shape = -1;
             }
             if (typename T::Glass* gl = dynamic_cast<typename T::Glass*>(b->material)) {
@@ -197,7 +266,7 @@ template <class T>
 int intersect_all(const double* rays6, int n, double* t_out) {
     int count = 0;
     with_scene<T>([&](typename T::Scene* s) {
-        count = s->body_count;
+        count = body_count_of(s->objects, s->body_count);
         for (int i = 0; i < n; i++) {
             typename T::Ray ray = make_ray<T>(rays6 + 6 * i);
             for (int b = 0; b < count; b++) t_out[(size_t)i * count + b] = s->objects[b]->shape->intersect(ray);
@@ -252,7 +321,9 @@ long long render_custom(const ptor_body* bodies, int n, int W, int H, int first_
         for (int i = 0; i < n; i++) {
             const ptor_body& b = bodies[i];
             typename T::Shape* sh;
-            if (b.shape == PTOR_PLANE)
+            if (b.shape == PTOR_RECTANGLE)
+                sh = make_rectangle<T>(b);
+            else if (b.shape == PTOR_PLANE)
                 sh = new typename T::Plane(V3(b.center[0], b.center[1], b.center[2]), V3(b.normal[0], b.normal[1], b.normal[2]));
             else
                 sh = new typename T::Sphere(V3(b.center[0], b.center[1], b.center[2]), b.radius);
@@ -275,7 +346,7 @@ long long render_custom(const ptor_body* bodies, int n, int W, int H, int first_
         sc.width = W;
         sc.height = H;
         sc.body_count = n;
-        sc.objects = objs.data();
+        set_objects(sc.objects, objs);
         {
             typename T::Renderer r(sc);
             set_mode<T>(mode, seed, 0, 0);
@@ -300,6 +371,9 @@ extern "C" {
 // ptor_render on a caller-supplied body list (constructor arguments, see render_custom).
 long long ptor_render_custom(int prog, const ptor_body* bodies, int n, int W, int H, int first_it, int n_it, int mode,
                              uint64_t seed, double* buffer_out) {
+    if (prog == 2) return render_custom<RT3>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out);
+    for (int i = 0; i < n; i++)
+        if (bodies[i].shape == PTOR_RECTANGLE) return -1;  // only raytrace3.cpp has the shape
     return prog == 0 ? render_custom<PT>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out)
                      : render_custom<NEE>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out);
 }
@@ -309,13 +383,15 @@ int ptor_set_scratch(const char* dir) {
     return 0;
 }
 
-// prog: 0 = main.cpp, 1 = next_event.cpp.  Returns body count.
+// prog: 0 = main.cpp, 1 = next_event.cpp, 2 = raytrace3.cpp.  Returns body count.
 int ptor_scene_bodies(int prog, ptor_body* out, int cap, ptor_camera* cam) {
+    if (prog == 2) return scene_bodies<RT3>(out, cap, cam);
     return prog == 0 ? scene_bodies<PT>(out, cap, cam) : scene_bodies<NEE>(out, cap, cam);
 }
 
 // t_out[n][body_count]: Shape::intersect of every body, in array order. Returns body count.
 int ptor_intersect_all(int prog, const double* rays6, int n, double* t_out) {
+    if (prog == 2) return intersect_all<RT3>(rays6, n, t_out);
     return prog == 0 ? intersect_all<PT>(rays6, n, t_out) : intersect_all<NEE>(rays6, n, t_out);
 }
 
@@ -384,6 +460,7 @@ int ptor_bounce(int prog, int body, const double* ray6, const double* normal3, c
 // Renderer's private buffer after n_it iterations. Returns the number of rand() calls.
 long long ptor_render(int prog, int W, int H, int first_it, int n_it, int mode, uint64_t seed,
                       const int* script, int script_len, double* buffer_out) {
+    if (prog == 2) return render<RT3>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out);
     return prog == 0 ? render<PT>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out)
                      : render<NEE>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out);
 }

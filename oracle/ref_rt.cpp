@@ -36,8 +36,8 @@ struct RtState {
 
 thread_local RtState g;
 
-void* g_addr_getray[2] = {0, 0};
-void* g_addr_iadd[2] = {0, 0};
+void* g_addr_getray[3] = {0, 0, 0};
+void* g_addr_iadd[3] = {0, 0, 0};
 
 }  // namespace
 
@@ -121,7 +121,7 @@ PTOR_NOINST void __cyg_profile_func_enter(void* fn, void*) {
     g_dbg[0]++;
     if (g.mode != PTOR_MODE_PIXEL) return;
     g_dbg[1]++;
-    if (fn == g_addr_getray[0] || fn == g_addr_getray[1]) {
+    if (fn == g_addr_getray[0] || fn == g_addr_getray[1] || fn == g_addr_getray[2]) {
         // Camera::getRay is called exactly once per pixel, first thing in the pixel body.
         ptor_rng_init(&g.rng, g.seed, g.iteration, PTOR_DOM_PIXEL, g.pixel++);
         g.in_pixel = true; g_dbg[2]++;
@@ -130,7 +130,7 @@ PTOR_NOINST void __cyg_profile_func_enter(void* fn, void*) {
 
 PTOR_NOINST void __cyg_profile_func_exit(void* fn, void*) {
     if (g.mode != PTOR_MODE_PIXEL) return;
-    if (fn == g_addr_iadd[0] || fn == g_addr_iadd[1]) {
+    if (fn == g_addr_iadd[0] || fn == g_addr_iadd[1] || fn == g_addr_iadd[2]) {
         // V3::iadd is called exactly once per pixel, last thing in the pixel body.
         g.in_pixel = false; g_dbg[3]++;
     }

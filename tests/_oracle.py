@@ -17,26 +17,35 @@ REF_HOOKED_SO = os.path.join(ROOT, "oracle", "_ref", "libptref_hooked.so")
 
 MODE_SEQ, MODE_SCRIPT, MODE_PIXEL = 0, 1, 2
 EST_PT, EST_NEE = 0, 1
-SPHERE, PLANE = 0, 1
+SPHERE, PLANE, RECTANGLE = 0, 1, 2
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3
 RAND_MAX = 2147483647
 BRDF_N = 90 * 90 * 180
 
 
+_BODY_FIELDS_136 = [
+    ("shape", C.c_int32),
+    ("material", C.c_int32),
+    ("center", C.c_double * 3),
+    ("normal", C.c_double * 3),
+    ("radius", C.c_double),
+    ("color", C.c_double * 3),
+    ("emission", C.c_double * 3),
+    ("ior", C.c_double),
+    ("reflection", C.c_double),
+    ("brdf_id", C.c_int32),
+    ("pad", C.c_int32),
+]
+
+
 class Body(C.Structure):
-    _fields_ = [
-        ("shape", C.c_int32),
-        ("material", C.c_int32),
-        ("center", C.c_double * 3),
-        ("normal", C.c_double * 3),
-        ("radius", C.c_double),
-        ("color", C.c_double * 3),
-        ("emission", C.c_double * 3),
-        ("ior", C.c_double),
-        ("reflection", C.c_double),
-        ("brdf_id", C.c_int32),
-        ("pad", C.c_int32),
-    ]
+    _fields_ = _BODY_FIELDS_136 + [("corners", C.c_double * 12)]  # rectangles: p1..p4 (raytrace3.cpp:254)
+
+
+class Body136(C.Structure):
+    """The record without corner points, as stored in the golden files made before rectangles."""
+
+    _fields_ = _BODY_FIELDS_136
 
 
 class Camera(C.Structure):
@@ -177,6 +186,12 @@ class Port:
         v = np.ascontiguousarray(v, dtype=np.float64)
         out = np.zeros(3)
         self.lib.por_plane_normal(_p(v), _p(out))
+        return out
+
+    def rect_normal(self, corners12):
+        c = np.ascontiguousarray(corners12, dtype=np.float64)
+        out = np.zeros(3)
+        self.lib.por_rect_normal(_p(c), _p(out))
         return out
 
     def bounce(self, s, body, ray6, normal3, script):
@@ -326,13 +341,21 @@ class Ref:
 
 
 def bodies_to_bytes(bodies, n):
-    """Body array -> uint8 numpy array (the 136-byte records, exact)."""
+    """Body array -> uint8 numpy array (the 232-byte records, exact)."""
     return np.frombuffer(bytes(bodies)[: n * C.sizeof(Body)], dtype=np.uint8).copy()
 
 
-def bodies_from_bytes(raw):
-    n = raw.size // C.sizeof(Body)
-    arr = (Body * n).from_buffer_copy(raw.tobytes())
+def bodies_from_bytes(raw, record=136):
+    """record: bytes per body in `raw` (136: golden files without corner points)."""
+    if record == C.sizeof(Body):
+        n = raw.size // record
+        return (Body * n).from_buffer_copy(raw.tobytes()), n
+    assert record == C.sizeof(Body136)
+    n = raw.size // record
+    old = (Body136 * n).from_buffer_copy(raw.tobytes())
+    arr = (Body * n)()
+    for i in range(n):
+        C.memmove(C.byref(arr[i]), C.byref(old[i]), record)
     return arr, n
 
 
@@ -344,6 +367,10 @@ def constructed(port, bodies, n):
         out[i] = Body.from_buffer_copy(bodies[i])
         if out[i].shape == PLANE:
             nn = port.plane_normal(np.array(list(bodies[i].normal)))
+            for k in range(3):
+                out[i].normal[k] = nn[k]
+        if out[i].shape == RECTANGLE:  # normal = normalize((p3-p1) x (p2-p1)), raytrace3.cpp:260
+            nn = port.rect_normal(np.array(list(bodies[i].corners)))
             for k in range(3):
                 out[i].normal[k] = nn[k]
     return out
