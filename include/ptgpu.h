@@ -31,7 +31,8 @@ typedef enum pt_status {
     PT_ERR_UNSUPPORTED = -5
 } pt_status;
 
-enum { PT_SPHERE = 0, PT_PLANE = 1 };                              /* Sphere main.cpp:198, Plane main.cpp:171 */
+enum { PT_SPHERE = 0, PT_PLANE = 1, PT_RECTANGLE = 2 };           /* Sphere main.cpp:198, Plane main.cpp:171,
+                                                                      Rectangle raytrace3.cpp:244 (PT_EST_PT only) */
 enum { PT_DIFFUSE = 0, PT_CHROME = 1, PT_GLASS = 2, PT_MEASURED = 3 }; /* Material :230, Chrome :257, Glass :269,
                                                                       MatusikBRDF.h:37 */
 enum { PT_EST_PT = 0, PT_EST_NEE = 1 };                            /* main.cpp trace() / next_event.cpp iterate() */
@@ -40,6 +41,10 @@ enum { PT_EST_PT = 0, PT_EST_NEE = 1 };                            /* main.cpp t
 #define PT_F_LIGHT_TRUE_CENTER 1u /* NEE shadow rays start at the light's real centre.  Default (flag
                                      clear) reproduces next_event.cpp:167,406-407, where
                                      light->shape->center reads the never-assigned base member (0,0,0). */
+
+#define PT_F_RAYTRACE3 2u /* PT_EST_PT as raytrace3.cpp runs it (shoot_trace = false, raytrace3.cpp:555): a hit
+                             needs t > 0.0000001L (:776) instead of t > 0, and a level returns
+                             color * (trace(next) + V3()) + emission (:805,840). */
 
 /* One Body (main.cpp:309-318): a Shape plus a Material, by value.
  * `normal` is the Plane constructor ARGUMENT (main.cpp:176-179); the library normalises it the way
@@ -56,6 +61,8 @@ typedef struct pt_body {
     double reflection; /* Glass only */
     int32_t brdf_id;   /* PT_MEASURED only: table slot 0..PT_MAX_BRDF-1, else -1 */
     int32_t reserved;
+    double corners[12]; /* PT_RECTANGLE only: the constructor arguments p1, p2, p3, p4 (raytrace3.cpp:254);
+                           `normal` is then an output of pt_body_construct, center and radius are unused */
 } pt_body;
 
 /* Camera(origin, topleft, topright, bottomleft): main.cpp:144-152. */
@@ -93,7 +100,8 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out);
 int pt_scene_destroy(pt_scene* scene);
 
 /* Apply the Shape constructors to one body in place: a Plane stores normalize(normal)
- * (main.cpp:176-179); a Sphere is unchanged.  pt_scene_create does this to its own copy. Host only. */
+ * (main.cpp:176-179); a Sphere is unchanged; a Rectangle stores normalize((p3-p1) x (p2-p1)) in
+ * `normal` (raytrace3.cpp:260).  pt_scene_create does this to its own copy. Host only. */
 int pt_body_construct(pt_body* body);
 
 /* The bodies as stored after construction (plane normals normalised). Returns the count. */

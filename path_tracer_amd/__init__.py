@@ -15,10 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PTGPU_LIB selects another build of the same ABI (development builds with counters)
 LIB_PATH = os.environ.get("PTGPU_LIB") or os.path.join(_HERE, "libptgpu.so")
 
-SPHERE, PLANE = 0, 1
+SPHERE, PLANE, RECTANGLE = 0, 1, 2
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3
 EST_PT, EST_NEE = 0, 1
 F_LIGHT_TRUE_CENTER = 1
+F_RAYTRACE3 = 2  # raytrace3.cpp's path tracer: hit threshold 1e-7, see include/ptgpu.h
 BRDF_TABLE_DOUBLES = 3 * 90 * 90 * 180
 DOM_PIXEL, DOM_ROW, DOM_FRAME, DOM_SEQ = 0, 1, 2, 3
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
@@ -43,6 +44,7 @@ class Body(C.Structure):
         ("reflection", C.c_double),
         ("brdf_id", C.c_int32),
         ("reserved", C.c_int32),
+        ("corners", C.c_double * 12),
     ]
 
 

@@ -1,9 +1,11 @@
-// Drop-in executables for the reference's two programs:
+// Drop-in executables for three of the reference's programs:
 //   main        <width> <height> <iterations> <thread count>   (main.cpp:460-471, 642-656)
 //   next_event  <width> <height> <iterations> <thread count>   (next_event.cpp:587-598, 701-712)
+//   raytrace3   <width> <height> <iterations> <thread count>   (raytrace3.cpp:906-918, 1021-1036;
+//               main's command line, worker split and save(), its own scene and hit threshold)
 // Same positional arguments, same hard-coded scenes, same output file names and PPM bytes; the
-// per-pixel estimator runs on the GPU through the ptgpu C ABI.  Built twice from this file
-// (-DPT_PROG_NEE selects next_event).
+// per-pixel estimator runs on the GPU through the ptgpu C ABI.  Built three times from this file
+// (-DPT_PROG_NEE selects next_event, -DPT_PROG_RT3 raytrace3).
 //
 // <thread count> keeps the reference's arithmetic: each of the T workers renders
 // iterations/T full frames into a private buffer and the buffers are summed (main.cpp:436-458);
@@ -63,7 +65,11 @@ int main(int argc, const char* argv[]) {
     int per_worker = iterations / thread_count;                          // next_event.cpp:703
     if (out.empty()) out = "output.ppm";                                 // next_event.cpp:535
 #else
+#ifdef PT_PROG_RT3
+    const char* preset = "raytrace3";
+#else
     const char* preset = "main32";
+#endif
     int per_worker = (int)((double)iterations / (double)thread_count);   // main.cpp:644 (double -> int parameter)
     if (out.empty()) out = "output_" + std::to_string(iterations) + ".ppm";  // main.cpp:411-412
 #endif

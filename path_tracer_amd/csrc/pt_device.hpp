@@ -51,7 +51,7 @@ constexpr int kGroupBodies = 8;  // member slots per group of the grouped scan
 constexpr int kSuperGroups = 8;  // groups per super-group
 constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
-enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4 };  // 2..4: device-only, normal = +-e_k
+enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4, kRect = 5 };  // 2..4: device-only, normal = +-e_k; 5: Rectangle
 enum { kDiffuse = 0, kChrome = 1, kGlass = 2, kMeasured = 3 };
 enum { kEstPT = 0, kEstNEE = 1 };
 enum { kDomPixel = 0, kDomRow = 1, kDomFrame = 2, kDomSeq = 3 };
@@ -176,6 +176,15 @@ PTD_INLINE double origin0_term(const DGeom& g) {
     return __hiloint2double(g.pad[2], g.pad[1]);
 }
 
+// Rectangle (raytrace3.cpp:244-276) as its constructor stores it: p1, p3, v1 = normalize(p2 - p1),
+// v3 = normalize(p4 - p3), normal = normalize((p3 - p1) x (p2 - p1)).  The body's DGeom carries the
+// normal (shape kRect) and, in pad[0], the index of its DRect.
+struct DRect {  // 128 bytes
+    double p1[3], p3[3], v1[3], v3[3], n[3];
+    int32_t body;
+    int32_t pad;
+};
+
 // Per-ray data of the single-precision sphere screen (see make_rayf).
 struct RayF {
     float ox, oy, oz, dx, dy, dz;
@@ -220,7 +229,11 @@ struct DScene {
     const DGeom* scan_spheres;
     const DScreen2* scan_screen;
     const DScreen2* scan_screen0;  // the same pairs with |c|^2 - r^2 in place of r^2: the screen from the origin (0,0,0)
-    int32_t n_planes, n_spheres;
+    const DRect* scan_rects;       // rectangles in ascending body order
+    int32_t n_planes, n_spheres, n_rects;
+    // A hit needs t > hit_eps: 0 (main.cpp:378, next_event.cpp:502) or, for raytrace3.cpp:776, the
+    // largest double below 0.0000001L (t > 0.0000001L for a double t is t > that double).
+    double hit_eps;
     // Slab of axis k (bit k of slab_mask): the two axis-aligned planes of that axis with the
     // smallest and the largest coordinate, bodies slab_ilo[k] and slab_ihi[k].  slab_big[k] bounds
     // |o_k| for the one-division form (see scan_slab).
@@ -279,8 +292,31 @@ PTD_INLINE double intersect_sphere(const DGeom& g, V3 o, V3 d) {
 // are signed zeros), and their quotient is (c_k - o_k) / d_k bit for bit whenever it is non-zero;
 // zero or negative results never win the scan.  Valid for finite rays.
 
+// Rectangle::intersect raytrace3.cpp:283-308: the plane test, `t < 1.0L` counts as a miss, then
+// the hit point must lie on the positive side of v1 seen from p1 and of v3 seen from p3 (both
+// differences normalised first, as the reference does — a hit exactly on p1 or p3 normalises a zero
+// vector and misses).  Returns false where the reference returns -1.
+PTD_INLINE bool scan_rect(const DRect& r, V3 o, V3 d, double& t) {
+    const V3 n = ld3(r.n), p1 = ld3(r.p1);
+    const double n_dot_u = dot(n, d);
+    const double n_dot_p0 = dot(n, sub(p1, o));
+    t = n_dot_p0 / n_dot_u;
+    bool ok = !((n_dot_u > -0.00001) && (n_dot_u < 0.00001)) && !(t < 1.0);
+    if (__builtin_amdgcn_ballot_w64(ok) != 0) {
+        const V3 hit = add(o, muls(d, t));
+        const V3 v4 = normalize(sub(hit, p1));
+        const V3 v5 = normalize(sub(hit, ld3(r.p3)));
+        ok = ok && (dot(ld3(r.v1), v4) > 0.0) && (dot(ld3(r.v3), v5) > 0.0);
+    }
+    return ok;
+}
+
 // Exact Shape::intersect value, signed zeros included (diagnostics).
-PTD_INLINE double intersect_body(const DGeom& g, V3 o, V3 d) {
+PTD_INLINE double intersect_body(const DScene& S, const DGeom& g, V3 o, V3 d) {
+    if (g.shape == kRect) {
+        double t;
+        return scan_rect(S.scan_rects[g.pad[0]], o, d, t) ? t : -1.0;
+    }
     return g.shape == kSphere ? intersect_sphere(g, o, d) : intersect_plane(g, o, d);
 }
 
@@ -360,9 +396,9 @@ PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t) {
 //  3. spheres, two per step: the packed single-precision screen decides per wave whether either
 //     needs its exact FP64 evaluation, merged with the same explicit rule.
 // Records are read at wave-uniform addresses (scalar loads); the shape switch is a scalar branch.
-PTD_INLINE void merge_hit(bool ok, double t, int i, int skip, int& hit, double& mint) {
+PTD_INLINE void merge_hit(bool ok, double t, int i, int skip, double eps, int& hit, double& mint) {
     // bitwise on purpose: plain compares combined on the scalar unit, no divergent branches
-    const bool take = ok & (t > 0.0) & ((t < mint) | ((t == mint) & (i > hit))) & (i != skip);
+    const bool take = ok & (t > eps) & ((t < mint) | ((t == mint) & (i > hit))) & (i != skip);
     mint = take ? t : mint;
     hit = take ? i : hit;
 }
@@ -418,6 +454,7 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
     PT_PROF(kProfScanPlanes);
     if (ORIGIN0) o = mk(0.0, 0.0, 0.0);  // c - 0.0 folds to c
     const int n_planes = S.n_planes;
+    const double eps = S.hit_eps;  // slabs exist only in scenes with hit_eps == 0
     for (int k = 0; k < n_planes; ++k) {
         const DGeom g = planes[k];
         double t;
@@ -437,7 +474,7 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
                 break;
         }
         const int i = g.pad[0];
-        bool take = ok && (t > 0.0) && (t <= mint) && (i != skip);
+        bool take = ok && (t > eps) && (t <= mint) && (i != skip);
         mint = take ? t : mint;
         hit = take ? i : hit;
     }
@@ -471,12 +508,23 @@ PTD_INLINE void sphere_possible2_masks_origin0(float dx, float dy, float dz, flo
     m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
     m1 = PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b));
 }
-template <bool ORIGIN0>
+// RECTS: the scene may hold rectangles (plain path tracing only; the next-event kernels are built
+// without them).
+template <bool ORIGIN0, bool RECTS = false>
 PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ planes, const DGeom* __restrict__ spheres,
                                  const DScreen2* __restrict__ screen, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     scan_all_planes<ORIGIN0>(S, planes, o, d, skip, hit, mint);
+    if (RECTS) {
+        const DRect* __restrict__ rects = S.scan_rects;
+        const int n_rects = S.n_rects;
+        for (int k = 0; k < n_rects; ++k) {
+            double t;
+            const bool ok = scan_rect(rects[k], o, d, t);
+            merge_hit(ok, t, rects[k].body, skip, S.hit_eps, hit, mint);
+        }
+    }
     const int n_spheres = S.n_spheres;
     if (n_spheres > 0) {
         PT_PROF(kProfScanScreen);
@@ -497,15 +545,16 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
                 const DGeom g = spheres[2 * k + h];
                 double t;
                 const bool ok = ORIGIN0 ? scan_sphere_exact_origin0(g, d, t) : scan_sphere_exact(g, o, d, t);
-                merge_hit(ok, t, g.pad[0], skip, hit, mint);
+                merge_hit(ok, t, g.pad[0], skip, S.hit_eps, hit, mint);
             }
         }
     }
     tmin = mint;
     return hit;
 }
+template <bool RECTS = false>
 PTD_INLINE int nearest_hit(const DScene& S, V3 o, V3 d, int skip, double& tmin) {
-    return nearest_hit_lists<false>(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, skip, tmin);
+    return nearest_hit_lists<false, RECTS>(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, skip, tmin);
 }
 // The scan of a shadow ray towards `d` with `light` left out (next_event.cpp:405-426).  Unless the
 // scene asks for the lights' real centres every shadow ray starts at (0,0,0).
@@ -958,7 +1007,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 #pragma unroll 1
     for (; n < kMaxDepth; ++n) {
         double mint;
-        int hit = nearest_hit(S, o, d, -1, mint);
+        int hit = nearest_hit<EST == kEstPT>(S, o, d, -1, mint);
         if (hit < 0) break;
         V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
         PT_PROF(kProfRecords);
@@ -972,6 +1021,9 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 #pragma unroll 1
         for (int k = n - 1; k >= 0; --k) {
             DMat m = mat[rec.body(k)];
+            // raytrace3.cpp:805,840: color * (trace(next) + direct_color) + emission with
+            // direct_color = V3(): the added zero turns a -0 into +0
+            if (S.flags & 2u) L = add(L, mk(0.0, 0.0, 0.0));
             L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
         }
         R.rgb = L;

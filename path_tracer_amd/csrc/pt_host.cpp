@@ -38,6 +38,14 @@ struct Builder {
         b->radius = r;
         return b;
     }
+    // Rectangle(p1, p2, p3, p4) raytrace3.cpp:254
+    pt_body* rectangle(const double (&c)[12]) {
+        pt_body* b = next();
+        if (!b) return nullptr;
+        b->shape = PT_RECTANGLE;
+        memcpy(b->corners, c, sizeof c);
+        return b;
+    }
     pt_body* plane(double cx, double cy, double cz, double nx, double ny, double nz) {
         pt_body* b = next();
         if (!b) return nullptr;
@@ -122,6 +130,28 @@ void common_bodies(Builder& B, bool nee) {
         diffuse(B.plane(-1.8, 4.4, 2.4, n[0], n[1], n[2]), 0.0, 0.8, 0.0);  // main.cpp:537
     ref_normalize(-1.0, -1.0, -1.0, n);
     diffuse(B.plane(1.8, 4.4, 2.4, n[0], n[1], n[2]), 0.8, 0.0, 0.0);       // top-right divider :594 / :682
+}
+
+// raytrace3.cpp:929-985: two balls, six rectangular walls (the "front" wall repeats the back wall's
+// plane), two sphere lights and a rectangular ceiling light sharing one light material.
+void scene_raytrace3(Builder& B) {
+    glass(B.sphere(1.0, 2.0, 0.0, 0.5), 1.0, 1.0, 1.0, 1.5, 0.1);  // :931-934
+    chrome(B.sphere(-1.1, 2.8, 0.0, 0.5), 0.8, 0.8, 0.8);          // :936-939
+    diffuse(B.rectangle({-1.9, 4.5, -0.5, 1.9, 4.5, -0.5, 1.9, -2.5, -0.5, -1.9, -2.5, -0.5}), 0.9, 0.9, 0.9);  // floor :941-944
+    diffuse(B.rectangle({-1.9, 4.5, 2.5, 1.9, 4.5, 2.5, 1.9, 4.5, -0.5, -1.9, 4.5, -0.5}), 0.9, 0.9, 0.9);      // back  :945-948
+    diffuse(B.rectangle({-1.9, -2.5, 2.5, -1.9, 4.5, 2.5, -1.9, 4.5, -0.5, -1.9, -2.5, -0.5}), 0.9, 0.5, 0.5);  // left  :949-952
+    diffuse(B.rectangle({1.9, 4.5, 2.5, 1.9, -2.5, 2.5, 1.9, -2.5, -0.5, 1.9, 4.5, -0.5}), 0.5, 0.5, 0.9);      // right :953-956
+    diffuse(B.rectangle({1.9, 4.5, 2.5, -1.9, 4.5, 2.5, -1.9, -2.5, 2.5, 1.9, -2.5, 2.5}), 0.9, 0.9, 0.9);      // top   :957-960
+    diffuse(B.rectangle({1.9, 4.5, 2.5, -1.9, 4.5, 2.5, -1.9, 4.5, -0.5, 1.9, 4.5, -0.5}), 0.9, 0.9, 0.9);      // front :961-964
+    auto light = [](pt_body* b) {  // Material(V3(0.2, 0.187, 0.169), V3(2.0, 1.87, 1.69)) :966
+        if (!b) return;
+        b->material = PT_DIFFUSE;
+        Builder::set3(b->color, 0.2, 0.187, 0.169);
+        Builder::set3(b->emission, 2.0, 1.87, 1.69);
+    };
+    light(B.sphere(-0.63333, 4.5, 2.1, 0.1));  // :968-970
+    light(B.sphere(0.63333, 4.5, 2.1, 0.1));   // :972-974
+    light(B.rectangle({1.4, 3.5, 2.5, -1.4, 3.5, 2.5, -1.4, -2.5, 2.5, 1.4, -2.5, 2.5}));  // top light :976-979
 }
 
 // next_event.cpp:605-689, array order :687
@@ -211,6 +241,15 @@ int pt_body_construct(pt_body* b) {
         ref_normalize(b->normal[0], b->normal[1], b->normal[2], n);
         memcpy(b->normal, n, sizeof n);
     }
+    if (b->shape == PT_RECTANGLE) {
+        // this->normal = p3.sub(p1).cross(p2.sub(p1)).normalize()  raytrace3.cpp:260, cross :128-133
+        const double* c = b->corners;
+        const double ax = c[6] - c[0], ay = c[7] - c[1], az = c[8] - c[2];
+        const double bx = c[3] - c[0], by = c[4] - c[1], bz = c[5] - c[2];
+        double n[3];
+        ref_normalize((ay * bz) - (az * by), (az * bx) - (ax * bz), (ax * by) - (ay * bx), n);
+        memcpy(b->normal, n, sizeof n);
+    }
     return PT_OK;
 }
 
@@ -229,6 +268,10 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
     } else if (s == "main32") {
         desc->estimator = PT_EST_PT;
         scene_main32(B);
+    } else if (s == "raytrace3") {
+        desc->estimator = PT_EST_PT;
+        desc->flags = PT_F_RAYTRACE3;
+        scene_raytrace3(B);
     } else if (s == "pt15") {  // main.cpp's estimator on the 15-body / 2-light scene (bipath.cpp:556-558)
         desc->estimator = PT_EST_PT;
         scene_nee15(B);

@@ -134,7 +134,7 @@ PTD_INLINE void pending_eval(const DScene& S, Pending& pd, V3 o, V3 d, int skip,
             s.nx = g->nx;
             double t;
             const bool ok = scan_sphere_exact(s, o, d, t);
-            merge_hit(ok, t, idx, skip, hit, mint);
+            merge_hit(ok, t, idx, skip, 0.0, hit, mint);  // this pipeline is not used with a hit threshold
         }
     }
     pd.n = 0;

@@ -43,6 +43,16 @@ int fail(int code, const std::string& msg) {
             return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
+// V3::normalize on the host as the reference evaluates it (main.cpp:92-102): the reciprocal of the
+// length is formed in long double and narrowed before the three multiplications.
+void pt_normalize3(double x, double y, double z, double* o) {
+    const double len = std::sqrt(x * x + y * y + z * z);
+    const double inv = (double)(1.0L / (long double)len);
+    o[0] = x * inv;
+    o[1] = y * inv;
+    o[2] = z * inv;
+}
+
 constexpr int kBlock = 256;
 constexpr int kXStride = 8;  // the x running sum of a row is stored at every 8th column
 
@@ -250,7 +260,7 @@ __global__ void k_intersect_batch(DScene S, const double* __restrict__ rays6, in
     if (i >= n) return;
     V3 o = ld3(rays6 + 6 * (size_t)i), d = ld3(rays6 + 6 * (size_t)i + 3);
     double mint;
-    int hit = nearest_hit(S, o, d, skip, mint);
+    int hit = nearest_hit<true>(S, o, d, skip, mint);
     idx[i] = hit;
     t[i] = mint;
 }
@@ -259,7 +269,7 @@ __global__ void k_intersect_all(DScene S, const double* __restrict__ rays6, int 
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     V3 o = ld3(rays6 + 6 * (size_t)i), d = ld3(rays6 + 6 * (size_t)i + 3);
-    for (int b = 0; b < S.n_bodies; ++b) t_all[(size_t)i * S.n_bodies + b] = intersect_body(S.geom[b], o, d);
+    for (int b = 0; b < S.n_bodies; ++b) t_all[(size_t)i * S.n_bodies + b] = intersect_body(S, S.geom[b], o, d);
 }
 
 template <int EST, bool MEASURED>
@@ -403,7 +413,7 @@ struct pt_scene {
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
     DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_order;
-    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins;
+    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins, d_scan_rects;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
     DevBuf d_xs[2], d_ys[2], d_rowstart[2], d_npix[2], d_samples[2], d_accum;
@@ -417,6 +427,7 @@ struct pt_scene {
     double last_paths = 0;
     bool wf_sort = true;        // wavefront pipeline: reorder rays by key before every scan
     bool has_measured = false;  // any PT_MEASURED body: selects the kernel variant with the table lookup
+    bool has_rectangles = false;
     int pipeline = PT_PIPELINE_AUTO;
     int wf_batch = 1;  // iterations per wavefront batch
     DevBuf d_wf;       // one allocation carved into the wavefront state arrays
@@ -478,7 +489,15 @@ int upload_scene(pt_scene* s) {
     const int n = (int)s->bodies.size();
     std::vector<DGeom> geom(n);
     std::vector<DMat> mat(n);
+    std::vector<DRect> rects;
     float c1max = 0.0f, r2max = 0.0f;
+    // t > 0.0000001L (raytrace3.cpp:776) for a double t: t > the largest double not above the literal
+    double hit_eps = 0.0;
+    if (s->flags & PT_F_RAYTRACE3) {
+        const long double lit = 0.0000001L;
+        hit_eps = (double)lit;
+        if ((long double)hit_eps > lit) hit_eps = std::nextafter(hit_eps, 0.0);
+    }
     for (int i = 0; i < n; ++i) {
         const pt_body& b = s->bodies[i];
         DGeom g;
@@ -487,7 +506,29 @@ int upload_scene(pt_scene* s) {
         g.cy = b.center[1];
         g.cz = b.center[2];
         g.shape = b.shape;
-        if (b.shape == PT_PLANE) {
+        if (b.shape == PT_RECTANGLE) {
+            // Rectangle ctor raytrace3.cpp:254-265; pt_body_construct has stored the normal
+            g.shape = kRect;
+            g.nx = b.normal[0];
+            g.ny = b.normal[1];
+            g.nz = b.normal[2];
+            g.pad[0] = (int32_t)rects.size();
+            DRect r;
+            memset(&r, 0, sizeof r);
+            const double* c = b.corners;
+            double v1[3], v3[3];
+            pt_normalize3(c[3] - c[0], c[4] - c[1], c[5] - c[2], v1);
+            pt_normalize3(c[9] - c[6], c[10] - c[7], c[11] - c[8], v3);
+            for (int k = 0; k < 3; ++k) {
+                r.p1[k] = c[k];
+                r.p3[k] = c[6 + k];
+                r.v1[k] = v1[k];
+                r.v3[k] = v3[k];
+                r.n[k] = b.normal[k];
+            }
+            r.body = i;
+            rects.push_back(r);
+        } else if (b.shape == PT_PLANE) {
             g.nx = b.normal[0];
             g.ny = b.normal[1];
             g.nz = b.normal[2];
@@ -530,7 +571,7 @@ int upload_scene(pt_scene* s) {
     std::vector<char> in_slab(n, 0);
     DScene& D = s->ds;
     memset(&D, 0, sizeof D);
-    for (int axis = 0; axis < 3; ++axis) {
+    for (int axis = 0; axis < 3 && hit_eps == 0.0; ++axis) {  // the slab form assumes the threshold t > 0
         int lo = -1, hi = -1;
         auto coord = [&](int i) { return axis == 0 ? geom[i].cx : axis == 1 ? geom[i].cy : geom[i].cz; };
         for (int i = 0; i < n; ++i) {
@@ -555,7 +596,7 @@ int upload_scene(pt_scene* s) {
         g.pad[0] = i;
         if (g.shape == kSphere) {
             scan_spheres.push_back(g);
-        } else {
+        } else if (g.shape != kRect) {
             if (!in_slab[i]) scan_planes.push_back(g);
         }
     }
@@ -769,6 +810,14 @@ int upload_scene(pt_scene* s) {
     D.scan_screen0 = (const DScreen2*)s->d_scan_screen0.p;
     D.n_planes = n_planes;
     D.n_spheres = n_spheres;
+    D.hit_eps = hit_eps;
+    D.n_rects = (int)rects.size();
+    if (!rects.empty()) {
+        int rcr = s->d_scan_rects.ensure(sizeof(DRect) * rects.size());
+        if (rcr) return rcr;
+        HIP_TRY(hipMemcpy(s->d_scan_rects.p, rects.data(), sizeof(DRect) * rects.size(), hipMemcpyHostToDevice));
+        D.scan_rects = (const DRect*)s->d_scan_rects.p;
+    }
     if (s->has_measured) {
         // Bin edges of the table indices (MatusikBRDF.h:211-257) as thresholds, descending:
         // theta_half bin k starts at (k/90)^2 pi/2 and theta_diff bin k at k pi/180 (cosines),
@@ -951,9 +1000,16 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     s->bodies.assign(desc->bodies, desc->bodies + desc->body_count);
     for (size_t i = 0; i < s->bodies.size(); ++i) {
         pt_body& b = s->bodies[i];
-        if (b.shape != PT_SPHERE && b.shape != PT_PLANE) {
+        if (b.shape != PT_SPHERE && b.shape != PT_PLANE && b.shape != PT_RECTANGLE) {
             delete s;
             return fail(PT_ERR_INVALID, "pt_scene_create: unknown shape");
+        }
+        if (b.shape == PT_RECTANGLE) {
+            s->has_rectangles = true;
+            if (s->estimator != PT_EST_PT) {
+                delete s;
+                return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: rectangles exist only in raytrace3.cpp's path tracer (PT_EST_PT)");
+            }
         }
         if (b.material < PT_DIFFUSE || b.material > PT_MEASURED) {
             delete s;
@@ -963,6 +1019,10 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
         if (b.material == PT_MEASURED) s->has_measured = true;
         // Renderer ctor light list next_event.cpp:362-367
         if (b.emission[0] >= 1.0 || b.emission[1] >= 1.0 || b.emission[2] >= 1.0) s->lights.push_back((int32_t)i);
+    }
+    if ((s->flags & PT_F_RAYTRACE3) && s->estimator != PT_EST_PT) {
+        delete s;
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: PT_F_RAYTRACE3 applies to PT_EST_PT");
     }
     if (s->estimator == PT_EST_NEE && s->lights.empty()) {
         delete s;
@@ -995,6 +1055,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_scan_screen.release();
     s->d_scan_screen0.release();
     s->d_brdf_bins.release();
+    s->d_scan_rects.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
     for (int k = 0; k < 2; ++k) {
@@ -1096,6 +1157,8 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const bool use_wavefront = s->pipeline == PT_PIPELINE_WAVEFRONT ||
                                (s->pipeline == PT_PIPELINE_AUTO && (int)s->bodies.size() > kMaxBodiesFused);
+    if (use_wavefront && (s->has_rectangles || (s->flags & PT_F_RAYTRACE3)))
+        return fail(PT_ERR_UNSUPPORTED, "rectangles and the raytrace3 hit threshold need the fused pipeline (at most 127 bodies)");
     if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
     const int batch = use_wavefront ? s->wf_batch : s->batch;

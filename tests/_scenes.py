@@ -38,3 +38,80 @@ def scene_with_extra_planes(name, W, H, seed):
     d.body_count = n + len(extra)
     d._keep = bodies
     return d
+
+
+def rectangle_scene(seed, W, H, n_rect=7, n_sphere=5, n_plane=2):
+    """A seeded scene for raytrace3.cpp's path tracer: oblique and axis-aligned rectangles (some far,
+    some nearer than t = 1, which the reference's Rectangle::intersect treats as a miss), spheres,
+    planes, a few emitters; flag F_RAYTRACE3 (hit threshold 1e-7)."""
+    import numpy as np
+
+    rng = np.random.default_rng(4000 + seed)
+    d = pt.preset("raytrace3", W, H, seed=seed)
+    n = n_rect + n_sphere + n_plane
+    bodies = (pt.Body * n)()
+
+    def material(b):
+        kind = int(rng.integers(0, 3))
+        b.material = kind
+        b.brdf_id = -1
+        for c in range(3):
+            b.color[c] = float(rng.uniform(0.1, 0.95))
+            b.emission[c] = float(rng.uniform(0.5, 2.0)) if rng.uniform() < 0.3 else 0.0
+        if kind == pt.GLASS:
+            b.ior = float(rng.uniform(1.0, 1.8))
+            b.reflection = float(rng.uniform(0.0, 0.5))
+
+    k = 0
+    for _ in range(n_rect):
+        b = bodies[k]
+        k += 1
+        b.shape = pt.RECTANGLE
+        centre = rng.uniform([-1.5, 1.0, -0.5], [1.5, 5.0, 2.5])
+        if rng.uniform() < 0.5:  # axis-aligned
+            axis = int(rng.integers(0, 3))
+            u = np.zeros(3)
+            v = np.zeros(3)
+            u[(axis + 1) % 3] = rng.uniform(0.5, 3.0)
+            v[(axis + 2) % 3] = rng.uniform(0.5, 3.0)
+        else:
+            u = rng.normal(size=3)
+            u *= rng.uniform(0.5, 3.0) / np.linalg.norm(u)
+            v = np.cross(u, rng.normal(size=3))
+            v *= rng.uniform(0.5, 3.0) / np.linalg.norm(v)
+        # p1 -> p2 along u, p2 -> p3 along v, p3 -> p4 back along u (the corner order of raytrace3.cpp:942)
+        p1 = centre - 0.5 * u - 0.5 * v
+        pts = [p1, p1 + u, p1 + u + v, p1 + v]
+        for q in range(4):
+            for c in range(3):
+                b.corners[3 * q + c] = float(pts[q][c])
+        material(b)
+    for _ in range(n_sphere):
+        b = bodies[k]
+        k += 1
+        b.shape = pt.SPHERE
+        c = rng.uniform([-1.5, 1.0, -0.5], [1.5, 5.0, 2.5])
+        for q in range(3):
+            b.center[q] = float(c[q])
+        b.radius = float(rng.uniform(0.1, 0.7))
+        material(b)
+    for _ in range(n_plane):
+        b = bodies[k]
+        k += 1
+        b.shape = pt.PLANE
+        axis = int(rng.integers(0, 3))
+        sign = 1.0 if rng.uniform() < 0.5 else -1.0
+        c = [0.0, 0.0, 0.0]
+        c[axis] = -sign * float(rng.uniform(2.0, 5.0)) + (2.0 if axis == 1 else 0.0)
+        nrm = [0.0, 0.0, 0.0]
+        nrm[axis] = sign
+        if rng.uniform() < 0.5:
+            nrm = [float(x) for x in rng.normal(size=3)]
+        for q in range(3):
+            b.center[q] = c[q]
+            b.normal[q] = nrm[q]
+        material(b)
+    d.bodies = bodies
+    d.body_count = n
+    d._keep = bodies
+    return d

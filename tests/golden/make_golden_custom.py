@@ -46,7 +46,7 @@ def main():
         frame, draws = refh.render_custom(prog, ob, n, W, H, first, n_it, MODE_PIXEL, seed=seed)
         arrays[key + "_bodies"] = bodies_to_bytes(ob, n)
         arrays[key + "_frame"] = frame
-        meta.append(dict(key=key, prog=prog, bodies=n, W=W, H=H, first=first, n_it=n_it, seed=seed, draws=int(draws)))
+        meta.append(dict(key=key, prog=prog, body_record=C.sizeof(Body), bodies=n, W=W, H=H, first=first, n_it=n_it, seed=seed, draws=int(draws)))
         print(key, n, "bodies,", int(draws), "draws, mean", frame.mean())
     np.savez_compressed(os.path.join(HERE, "frames_custom.npz"), **arrays)
     with open(os.path.join(HERE, "frames_custom.json"), "w") as f:

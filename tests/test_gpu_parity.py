@@ -9,7 +9,7 @@ import pytest
 import path_tracer_amd as pt
 from _oracle import EST_NEE, EST_PT, MODE_PIXEL
 from conftest import GOLDEN, same_bits
-from _scenes import open_scene, scene_with_extra_planes
+from _scenes import open_scene, rectangle_scene, scene_with_extra_planes
 
 pytestmark = pytest.mark.gpu
 EST = {"main32": EST_PT, "nee15": EST_NEE, "pt15": EST_PT, "nee15_lit": EST_NEE, "bipath23": EST_NEE, "nee32": EST_NEE}
@@ -341,13 +341,14 @@ def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
 
     from conftest import ROOT
 
-    for prog, preset, (W, H, iters, threads) in (("next_event", "nee15", (40, 24, 7, 2)), ("main", "main32", (32, 32, 4, 1))):
+    for prog, preset, (W, H, iters, threads) in (("next_event", "nee15", (40, 24, 7, 2)), ("main", "main32", (32, 32, 4, 1)),
+                                                 ("raytrace3", "raytrace3", (36, 20, 6, 2))):
         out = str(tmp_path / f"{prog}.ppm")
         exe = os.path.join(ROOT, "path_tracer_amd", "bin", prog)
         subprocess.run([exe, str(W), str(H), str(iters), str(threads), "--seed", "77", "--out", out, "--quiet"],
                        check=True, timeout=120)
         r = pt.Renderer(pt.preset(preset, W, H, seed=77))
-        s = oracle_scene(port, r, W, H, 77)
+        s = oracle_scene(port, r, W, H, 77, flags=r.desc.flags)
         per = iters // threads
         total = np.zeros((H, W, 3))
         for k in range(threads):
@@ -449,12 +450,13 @@ def test_custom_scene_golden_frames(case):
     constructor arguments (ten lights, coincident/extra planes, open walls, 1000 bodies -> wavefront)."""
     import ctypes as C
 
+    import _oracle
+
     z = np.load(os.path.join(GOLDEN, "frames_custom.npz"))
-    raw = z[case["key"] + "_bodies"]
-    n = raw.size // C.sizeof(pt.Body)
+    args, n = _oracle.bodies_from_bytes(z[case["key"] + "_bodies"], case.get("body_record", 136))
     assert n == case["bodies"]
     d = pt.preset("nee15" if case["prog"] == 1 else "main32", case["W"], case["H"], seed=case["seed"])
-    bodies = (pt.Body * n).from_buffer_copy(raw.tobytes())
+    bodies = (pt.Body * n).from_buffer_copy(bytes(args))  # same field layout as the oracle's record
     d.bodies = bodies
     d.body_count = n
     d._keep = bodies
@@ -566,6 +568,72 @@ def test_random_scenes_match_oracle(port, seed):
         idx, t = r.intersect_batch(rays, skip=skip)
         _, idx0, t0 = port.intersect(s, rays, skip=skip)
         assert np.array_equal(idx, idx0) and same_bits(t, t0)
+    r.close()
+
+
+def test_raytrace3_golden(port):
+    """raytrace3.cpp's path tracer (Rectangle shape, hit threshold 1e-7) against vectors produced by
+    the reference itself: per-body intersect values, nearest hits, frames of its own scene and of
+    body lists built from constructor arguments (tests/golden/make_golden_raytrace3.py)."""
+    import _oracle
+
+    with open(os.path.join(GOLDEN, "raytrace3.json")) as f:
+        meta = json.load(f)
+    z = np.load(os.path.join(GOLDEN, "raytrace3.npz"))
+    r = pt.Renderer(pt.preset("raytrace3", 8, 8))
+    assert same_bits(r.intersect_all(z["rays"]), z["t_all"])
+    want = z["t_all"]
+    idx, t = r.intersect_batch(z["rays"])
+    for i in range(want.shape[0]):
+        best, bi = np.inf, -1
+        for b in range(want.shape[1]):
+            if want[i, b] > 1e-7 and want[i, b] <= best:
+                best, bi = want[i, b], b
+        assert idx[i] == bi, i
+        if bi >= 0:
+            assert t[i] == best
+    r.close()
+    for c in meta["frames"]:
+        r = pt.Renderer(pt.preset("raytrace3", c["W"], c["H"], seed=c["seed"]))
+        assert same_bits(r.render(c["first"], c["n_it"]), z["frame_" + c["key"]]), c["key"]
+        r.close()
+    for c in meta["custom"]:
+        d = rectangle_scene(c["seed"], c["W"], c["H"])
+        args, nb = _oracle.bodies_from_bytes(z[c["key"] + "_bodies"], meta["body_record"])
+        assert bytes(_oracle.bodies_to_bytes(args, nb)) == bytes(d._keep)  # the generator's scene, unchanged
+        r = pt.Renderer(d)
+        assert same_bits(r.render(c["first"], c["n_it"]), z[c["key"] + "_frame"]), c["key"]
+        r.close()
+
+
+@pytest.mark.parametrize("seed", range(10, 34))
+def test_random_rectangle_scenes_match_oracle(port, seed):
+    W, H = 36, 24
+    d = rectangle_scene(seed, W, H, n_rect=3 + seed % 9, n_sphere=seed % 7, n_plane=seed % 4)
+    r = pt.Renderer(d)
+    s = oracle_scene(port, r, W, H, seed, flags=pt.F_RAYTRACE3)
+    want, _ = port.render(s, MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
+    rng = np.random.default_rng(seed)
+    rays = np.concatenate([rng.uniform([-1.9, -2.5, -0.5], [1.9, 4.5, 2.5], (4000, 3)),
+                           rng.normal(size=(4000, 3)) * rng.uniform(0.1, 3.0, (4000, 1))], axis=1)
+    t_all, idx, t = port.intersect(s, rays)
+    assert same_bits(r.intersect_all(rays), t_all)
+    gi, gt = r.intersect_batch(rays)
+    assert np.array_equal(gi, idx) and same_bits(gt[idx >= 0], t[idx >= 0])
+    r.close()
+
+
+def test_rectangles_need_the_path_tracing_estimator():
+    d = rectangle_scene(1, 16, 16)
+    d.estimator = pt.EST_NEE
+    with pytest.raises(pt.PtError):
+        pt.Renderer(d)
+    d = rectangle_scene(1, 16, 16)
+    r = pt.Renderer(d)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    with pytest.raises(pt.PtError):
+        r.render(0, 1)
     r.close()
 
 

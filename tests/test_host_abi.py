@@ -40,6 +40,27 @@ def test_presets_equal_reference_scenes(name):
         assert a == b, (i, a, b)
 
 
+def test_raytrace3_preset_equals_reference_scene():
+    """The preset against the bodies raytrace3.cpp's main() builds (rectangle corners, and the normal
+    its Rectangle constructor stores), tests/golden/raytrace3.npz."""
+    import _oracle
+
+    with open(os.path.join(GOLDEN, "raytrace3.json")) as f:
+        meta = json.load(f)
+    z = np.load(os.path.join(GOLDEN, "raytrace3.npz"))
+    want, n = _oracle.bodies_from_bytes(z["scene_bodies"], meta["body_record"])
+    d = pt.preset("raytrace3", 16, 16)
+    assert d.body_count == n and d.estimator == pt.EST_PT and d.flags == pt.F_RAYTRACE3
+    for i in range(n):
+        b = pt.Body.from_buffer_copy(d.bodies[i])
+        assert pt.lib().pt_body_construct(C.byref(b)) == 0
+        w = want[i]
+        assert (b.shape, b.material) == (w.shape, w.material), i
+        for f in ("center", "normal", "color", "emission", "corners"):
+            assert [float(v).hex() for v in getattr(b, f)] == [float(v).hex() for v in getattr(w, f)], (i, f)
+        assert (b.radius, b.ior, b.reflection) == (w.radius, w.ior, w.reflection), i
+
+
 def test_save_ppm_bytes(tmp_path):
     with open(os.path.join(GOLDEN, "save.json")) as f:
         g = json.load(f)

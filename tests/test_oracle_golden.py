@@ -119,7 +119,7 @@ def test_custom_scene_frames_match_reference(port, golden_scene, case):
     1000 bodies): the restatement against frames the reference's own classes rendered from the same
     constructor arguments (tests/golden/make_golden_custom.py)."""
     z = np.load(os.path.join(GOLDEN, "frames_custom.npz"))
-    args, n = _oracle.bodies_from_bytes(z[case["key"] + "_bodies"])
+    args, n = _oracle.bodies_from_bytes(z[case["key"] + "_bodies"], case.get("body_record", 136))
     assert n == case["bodies"]
     stored = _oracle.constructed(port, args, n)
     _, _, cam = golden_scene("nee15")  # every program of the reference uses the same camera
@@ -135,3 +135,44 @@ def test_save_edge_values(port):
         g = json.load(f)
     buf = np.array([float.fromhex(h) for h in g["values_hex"]]).reshape(g["H"], g["W"], 3)
     assert port.save_ppm(buf, g["samples"], g["W"], g["H"]).decode() == g["ppm"]["1"]["text"]
+
+
+F_RAYTRACE3 = 2
+
+
+def raytrace3_golden():
+    with open(os.path.join(GOLDEN, "raytrace3.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLDEN, "raytrace3.npz"))
+
+
+def test_raytrace3_matches_reference(port, golden_scene):
+    """raytrace3.cpp (Rectangle shape, hit threshold 1e-7, tests/golden/make_golden_raytrace3.py): the
+    restatement against the reference's per-body intersect values and the frames of its iterate()."""
+    meta, z = raytrace3_golden()
+    bodies, n = _oracle.bodies_from_bytes(z["scene_bodies"], meta["body_record"])
+    assert n == meta["bodies"] == 11
+    _, _, cam = golden_scene("nee15")  # raytrace3.cpp:921-926 is the same camera
+    s = port.scene(bodies, n, cam, 8, 8, EST_PT, flags=F_RAYTRACE3)
+    t_all, idx, t = port.intersect(s, z["rays"])
+    assert same_bits(t_all, z["t_all"])
+    want = z["t_all"]
+    eps = 1e-7  # t > 0.0000001L: no t of this batch lies within an ulp of the threshold
+    for i in range(want.shape[0]):
+        best, bi = np.inf, -1
+        for b in range(n):
+            if want[i, b] > eps and want[i, b] <= best:
+                best, bi = want[i, b], b
+        assert idx[i] == bi
+    for c in meta["frames"]:
+        s = port.scene(bodies, n, cam, c["W"], c["H"], EST_PT, seed=c["seed"], flags=F_RAYTRACE3)
+        got, draws = port.render(s, MODE_PIXEL, c["first"], c["n_it"])
+        assert same_bits(got, z["frame_" + c["key"]]), c["key"]
+        assert draws == c["draws"]
+    for c in meta["custom"]:
+        args, nb = _oracle.bodies_from_bytes(z[c["key"] + "_bodies"], meta["body_record"])
+        stored = _oracle.constructed(port, args, nb)
+        s = port.scene(stored, nb, cam, c["W"], c["H"], EST_PT, seed=c["seed"], flags=F_RAYTRACE3)
+        got, draws = port.render(s, MODE_PIXEL, c["first"], c["n_it"])
+        assert same_bits(got, z[c["key"] + "_frame"]), c["key"]
+        assert draws == c["draws"]
