@@ -296,6 +296,18 @@ PTD_INLINE double intersect_sphere(const DGeom& g, V3 o, V3 d) {
 // the hit point must lie on the positive side of v1 seen from p1 and of v3 seen from p3 (both
 // differences normalised first, as the reference does — a hit exactly on p1 or p3 normalises a zero
 // vector and misses).  Returns false where the reference returns -1.
+// The two side tests compare v . normalize(w) with 0.  Scaling w by the positive factor 1/|w| and
+// rounding cannot move the dot product across zero unless it is already within rounding error of
+// it: with s = v . w and m = sum |v_k w_k|, the normalised form differs from s/|w| by less than
+// 2^-50 m/|w|, so |s| > 2^-48 m decides the sign of both (m above 2^-400 keeps |w|^2 and the
+// products clear of underflow, below 2^400 clear of overflow).  Undecided lanes — a hit within rounding
+// error of the edge line, or a degenerate w — take the reference's own sequence of operations.
+PTD_INLINE bool side_decided(V3 v, V3 w, bool& positive) {
+    const double s = dot(v, w);
+    const double m = (__builtin_fabs(v.x * w.x) + __builtin_fabs(v.y * w.y)) + __builtin_fabs(v.z * w.z);
+    positive = s > 0.0;
+    return (__builtin_fabs(s) > 0x1p-48 * m) && (m > 0x1p-400) && (m < 0x1p400);
+}
 PTD_INLINE bool scan_rect(const DRect& r, V3 o, V3 d, double& t) {
     const V3 n = ld3(r.n), p1 = ld3(r.p1);
     const double n_dot_u = dot(n, d);
@@ -304,9 +316,17 @@ PTD_INLINE bool scan_rect(const DRect& r, V3 o, V3 d, double& t) {
     bool ok = !((n_dot_u > -0.00001) && (n_dot_u < 0.00001)) && !(t < 1.0);
     if (__builtin_amdgcn_ballot_w64(ok) != 0) {
         const V3 hit = add(o, muls(d, t));
-        const V3 v4 = normalize(sub(hit, p1));
-        const V3 v5 = normalize(sub(hit, ld3(r.p3)));
-        ok = ok && (dot(ld3(r.v1), v4) > 0.0) && (dot(ld3(r.v3), v5) > 0.0);
+        const V3 w1 = sub(hit, p1), w3 = sub(hit, ld3(r.p3));
+        const V3 v1 = ld3(r.v1), v3 = ld3(r.v3);
+        bool pos1, pos3;
+        const bool dec1 = side_decided(v1, w1, pos1), dec3 = side_decided(v3, w3, pos3);
+        if (__builtin_amdgcn_ballot_w64(ok && !(dec1 && dec3)) != 0) {
+            const V3 v4 = normalize(w1);
+            const V3 v5 = normalize(w3);
+            if (!dec1) pos1 = dot(v1, v4) > 0.0;
+            if (!dec3) pos3 = dot(v3, v5) > 0.0;
+        }
+        ok = ok && pos1 && pos3;
     }
     return ok;
 }
