@@ -127,11 +127,14 @@ def main():
         n_measured += 1
     if args.pipeline:
         r.set_pipeline({"fused": pt.PIPELINE_FUSED, "wavefront": pt.PIPELINE_WAVEFRONT}[args.pipeline])
-    # algorithmic work per path: 14 flop per plane test, 19 per sphere test; 5 gather scans over all
-    # bodies (+ for NEE 5 shadow scans that leave out the chosen light, the last emitter)
+    # algorithmic work per path: 14 flop per plane test, 19 per sphere test, 56 per rectangle test
+    # (raytrace3.cpp:283-308: the plane test, the hit point, two differences, two normalisations, two
+    # dot products); 5 gather scans over all bodies (+ for NEE 5 shadow scans that leave out the
+    # chosen light, the last emitter)
     planes = sum(1 for i in range(desc.body_count) if desc.bodies[i].shape == pt.PLANE)
-    spheres = desc.body_count - planes
-    scan = 14.0 * planes + 19.0 * spheres
+    rectangles = sum(1 for i in range(desc.body_count) if desc.bodies[i].shape == pt.RECTANGLE)
+    spheres = desc.body_count - planes - rectangles
+    scan = 14.0 * planes + 19.0 * spheres + 56.0 * rectangles
     flop_per_path = 5.0 * scan
     rays_per_path = 5
     if desc.estimator == pt.EST_NEE:

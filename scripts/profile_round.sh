@@ -9,6 +9,7 @@ mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py --no-cpu > $out/bench_under_rocprof.json 2> $out/rocprof.log || { echo "rocprof pass failed"; tail -5 $out/rocprof.log; exit 1; }
 timeout -k 10 300 python3 bench.py > $out/bench_nee15.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
 timeout -k 10 200 python3 bench.py --no-cpu --scene main32 > $out/bench_main32.json 2>> $out/bench.err || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu --scene raytrace3 > $out/bench_raytrace3.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scene nee15_lit --iterations 720 > $out/bench_nee15_lit.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scene nee15_measured --iterations 720 > $out/bench_nee15_measured.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --width 3840 --height 2160 --iterations 256 > $out/bench_nee15_4k.json 2>> $out/bench.err || exit 1
