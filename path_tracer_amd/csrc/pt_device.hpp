@@ -783,6 +783,7 @@ struct Records {
     int8_t* bod;  // the fused kernels handle at most 127 bodies
     int stride;
     int tid;
+    PTD_INLINE void put_body(int k, int body) const { bod[k * stride + tid] = (int8_t)body; }
     PTD_INLINE void put(int k, V3 p, int body) const {
         pts[(k * 3 + 0) * stride + tid] = p.x;
         pts[(k * 3 + 1) * stride + tid] = p.y;
@@ -1031,7 +1032,10 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         if (hit < 0) break;
         V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
         PT_PROF(kProfRecords);
-        rec.put(n, point, hit);
+        if (EST == kEstPT && ELIDE)
+            rec.put_body(n, hit);  // plain path tracing reads only the bodies back (the render kernel keeps no points)
+        else
+            rec.put(n, point, hit);
     }
     PathResult R;
     R.nrec = n;

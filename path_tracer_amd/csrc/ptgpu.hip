@@ -150,11 +150,11 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
 // shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
-    __shared__ double s_pts[kMaxDepth * 3 * kBlock];
+    __shared__ double s_pts[EST == kEstPT ? 1 : kMaxDepth * 3 * kBlock];  // path tracing keeps no vertex positions
     __shared__ int8_t s_bod[kMaxDepth * kBlock];
     __shared__ uint16_t s_slots[COMPACT ? kBlock : 1];
     const int tid = threadIdx.x;
@@ -448,10 +448,11 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     P.tiles_y = (s->height + th - 1) / th;
     int total = P.tiles_x * P.tiles_y;
     P.owned_tiles = total > rank ? (total - rank + world - 1) / world : 0;
-    // batch: about 2^24 paths per launch, at most 64 iterations
+    // batch: about 2^24 paths per launch, at most 128 iterations (a rank that owns an eighth of a
+    // 1024x768 frame then still launches 1.3e7 paths at a time)
     size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
     size_t b = ((size_t)1 << 24) / per_it;
-    s->batch = (int)std::min<size_t>(64, std::max<size_t>(1, b));
+    s->batch = (int)std::min<size_t>(128, std::max<size_t>(1, b));
     // the wavefront pipeline keeps ~320 B of state per path in HBM (5.3 GB at 2^24 paths); large
     // batches also put more rays into every cell of the ray sort
     size_t wb = ((size_t)1 << 24) / per_it;
