@@ -486,398 +486,444 @@ int ensure_render_buffers(pt_scene* s) {
 
 constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
 
-int upload_scene(pt_scene* s) {
-    const int n = (int)s->bodies.size();
-    std::vector<DGeom> geom(n);
-    std::vector<DMat> mat(n);
+// Builds and uploads everything the kernels read about a scene: body and material records, the
+// compact scan lists with their slabs, the grouped layout of the tiled scan, the rectangle list, the
+// scene-wide flags.  One step per method, in the order of run().
+struct SceneUpload {
+    pt_scene* s;
+    DScene& D;
+    const int n;
+    std::vector<DGeom> geom;
+    std::vector<DMat> mat;
     std::vector<DRect> rects;
+    std::vector<DGeom> scan_planes, scan_spheres;
+    std::vector<DScreen2> scan_screen, scan_screen0;
+    std::vector<char> in_slab;
     float c1max = 0.0f, r2max = 0.0f;
-    // t > 0.0000001L (raytrace3.cpp:776) for a double t: t > the largest double not above the literal
     double hit_eps = 0.0;
-    if (s->flags & PT_F_RAYTRACE3) {
-        const long double lit = 0.0000001L;
-        hit_eps = (double)lit;
-        if ((long double)hit_eps > lit) hit_eps = std::nextafter(hit_eps, 0.0);
+    int n_planes = 0, n_spheres = 0;
+
+    explicit SceneUpload(pt_scene* scene)
+        : s(scene), D(scene->ds), n((int)scene->bodies.size()), geom(n), mat(n), in_slab(n, 0) {
+        memset(&D, 0, sizeof D);
     }
-    for (int i = 0; i < n; ++i) {
-        const pt_body& b = s->bodies[i];
-        DGeom g;
-        memset(&g, 0, sizeof g);
-        g.cx = b.center[0];
-        g.cy = b.center[1];
-        g.cz = b.center[2];
-        g.shape = b.shape;
-        if (b.shape == PT_RECTANGLE) {
-            // Rectangle ctor raytrace3.cpp:254-265; pt_body_construct has stored the normal
-            g.shape = kRect;
-            g.nx = b.normal[0];
-            g.ny = b.normal[1];
-            g.nz = b.normal[2];
-            g.pad[0] = (int32_t)rects.size();
-            DRect r;
-            memset(&r, 0, sizeof r);
-            const double* c = b.corners;
-            double v1[3], v3[3];
-            pt_normalize3(c[3] - c[0], c[4] - c[1], c[5] - c[2], v1);
-            pt_normalize3(c[9] - c[6], c[10] - c[7], c[11] - c[8], v3);
-            for (int k = 0; k < 3; ++k) {
-                r.p1[k] = c[k];
-                r.p3[k] = c[6 + k];
-                r.v1[k] = v1[k];
-                r.v3[k] = v3[k];
-                r.n[k] = b.normal[k];
-            }
-            r.body = i;
-            rects.push_back(r);
-        } else if (b.shape == PT_PLANE) {
-            g.nx = b.normal[0];
-            g.ny = b.normal[1];
-            g.nz = b.normal[2];
-            // axis-aligned unit normals take the one-division form of the scan
-            auto unit = [](double v) { return v == 1.0 || v == -1.0; };
-            if (unit(g.nx) && g.ny == 0.0 && g.nz == 0.0) g.shape = kPlaneX;
-            if (g.nx == 0.0 && unit(g.ny) && g.nz == 0.0) g.shape = kPlaneY;
-            if (g.nx == 0.0 && g.ny == 0.0 && unit(g.nz)) g.shape = kPlaneZ;
-        } else {
-            g.nx = b.radius * b.radius;  // Sphere ctor radius2 main.cpp:207
-            g.fcx = (float)g.cx;
-            g.fcy = (float)g.cy;
-            g.fcz = (float)g.cz;
-            g.fr2 = (float)g.nx;
-            c1max = std::max(c1max, std::fabs(g.fcx) + std::fabs(g.fcy) + std::fabs(g.fcz));
-            r2max = std::max(r2max, g.fr2);
+
+    // DGeom / DMat / DRect of every body, the hit threshold.
+    void body_records() {
+        // t > 0.0000001L (raytrace3.cpp:776) for a double t: t > the largest double not above the literal
+        hit_eps = 0.0;
+        if (s->flags & PT_F_RAYTRACE3) {
+            const long double lit = 0.0000001L;
+            hit_eps = (double)lit;
+            if ((long double)hit_eps > lit) hit_eps = std::nextafter(hit_eps, 0.0);
         }
-        geom[i] = g;
-        DMat m;
-        memset(&m, 0, sizeof m);
-        m.colr = b.color[0];
-        m.colg = b.color[1];
-        m.colb = b.color[2];
-        m.emr = b.emission[0];
-        m.emg = b.emission[1];
-        m.emb = b.emission[2];
-        m.ior = b.ior;
-        m.refl = b.reflection;
-        m.eta = 1.0 / b.ior;
-        m.material = b.material;
-        m.brdf_id = b.brdf_id;
-        m.emits = (b.emission[0] != 0.0) || (b.emission[1] != 0.0) || (b.emission[2] != 0.0);
-        mat[i] = m;
+        for (int i = 0; i < n; ++i) {
+            const pt_body& b = s->bodies[i];
+            DGeom g;
+            memset(&g, 0, sizeof g);
+            g.cx = b.center[0];
+            g.cy = b.center[1];
+            g.cz = b.center[2];
+            g.shape = b.shape;
+            if (b.shape == PT_RECTANGLE) {
+                // Rectangle ctor raytrace3.cpp:254-265; pt_body_construct has stored the normal
+                g.shape = kRect;
+                g.nx = b.normal[0];
+                g.ny = b.normal[1];
+                g.nz = b.normal[2];
+                g.pad[0] = (int32_t)rects.size();
+                DRect r;
+                memset(&r, 0, sizeof r);
+                const double* c = b.corners;
+                double v1[3], v3[3];
+                pt_normalize3(c[3] - c[0], c[4] - c[1], c[5] - c[2], v1);
+                pt_normalize3(c[9] - c[6], c[10] - c[7], c[11] - c[8], v3);
+                for (int k = 0; k < 3; ++k) {
+                    r.p1[k] = c[k];
+                    r.p3[k] = c[6 + k];
+                    r.v1[k] = v1[k];
+                    r.v3[k] = v3[k];
+                    r.n[k] = b.normal[k];
+                }
+                r.body = i;
+                rects.push_back(r);
+            } else if (b.shape == PT_PLANE) {
+                g.nx = b.normal[0];
+                g.ny = b.normal[1];
+                g.nz = b.normal[2];
+                // axis-aligned unit normals take the one-division form of the scan
+                auto unit = [](double v) { return v == 1.0 || v == -1.0; };
+                if (unit(g.nx) && g.ny == 0.0 && g.nz == 0.0) g.shape = kPlaneX;
+                if (g.nx == 0.0 && unit(g.ny) && g.nz == 0.0) g.shape = kPlaneY;
+                if (g.nx == 0.0 && g.ny == 0.0 && unit(g.nz)) g.shape = kPlaneZ;
+            } else {
+                g.nx = b.radius * b.radius;  // Sphere ctor radius2 main.cpp:207
+                g.fcx = (float)g.cx;
+                g.fcy = (float)g.cy;
+                g.fcz = (float)g.cz;
+                g.fr2 = (float)g.nx;
+                c1max = std::max(c1max, std::fabs(g.fcx) + std::fabs(g.fcy) + std::fabs(g.fcz));
+                r2max = std::max(r2max, g.fr2);
+            }
+            geom[i] = g;
+            DMat m;
+            memset(&m, 0, sizeof m);
+            m.colr = b.color[0];
+            m.colg = b.color[1];
+            m.colb = b.color[2];
+            m.emr = b.emission[0];
+            m.emg = b.emission[1];
+            m.emb = b.emission[2];
+            m.ior = b.ior;
+            m.refl = b.reflection;
+            m.eta = 1.0 / b.ior;
+            m.material = b.material;
+            m.brdf_id = b.brdf_id;
+            m.emits = (b.emission[0] != 0.0) || (b.emission[1] != 0.0) || (b.emission[2] != 0.0);
+            mat[i] = m;
+        }
     }
+
+    // A slab joins, per axis, the two axis-aligned planes with the smallest and the largest
+    // coordinate, provided the bound slab_big is usable.
+    void find_slabs() {
+        for (int axis = 0; axis < 3 && hit_eps == 0.0; ++axis) {  // the slab form assumes the threshold t > 0
+            int lo = -1, hi = -1;
+            auto coord = [&](int i) { return axis == 0 ? geom[i].cx : axis == 1 ? geom[i].cy : geom[i].cz; };
+            for (int i = 0; i < n; ++i) {
+                if (geom[i].shape != kPlaneX + axis) continue;
+                if (lo < 0 || coord(i) < coord(lo)) lo = i;
+                if (hi < 0 || coord(i) > coord(hi)) hi = i;
+            }
+            if (lo < 0 || !(coord(lo) < coord(hi))) continue;
+            // |o_k| < big  =>  |c - o_k| < 2^40 (c_hi - c_lo) for both planes
+            const double big = std::ldexp(coord(hi) - coord(lo), 40) - std::max(std::fabs(coord(lo)), std::fabs(coord(hi)));
+            if (!(big > 0.0) || !std::isfinite(big)) continue;
+            D.slab_big[axis] = big;
+            D.slab_mask |= 1 << axis;
+            D.slab_lo[axis] = coord(lo);
+            D.slab_hi[axis] = coord(hi);
+            D.slab_ilo[axis] = lo;
+            D.slab_ihi[axis] = hi;
+            in_slab[lo] = in_slab[hi] = 1;
+        }
+    }
+
     // Compact lists of the fused scan (body index in pad[0]), each in ascending body order: the
     // planes outside the slabs and the spheres; an odd sphere count is padded with a record whose
-    // screen never passes (r2 = -inf).  A slab joins, per axis, the two axis-aligned planes with
-    // the smallest and the largest coordinate, provided the bound slab_big is usable.
-    std::vector<DGeom> scan_planes, scan_spheres;
-    std::vector<char> in_slab(n, 0);
-    DScene& D = s->ds;
-    memset(&D, 0, sizeof D);
-    for (int axis = 0; axis < 3 && hit_eps == 0.0; ++axis) {  // the slab form assumes the threshold t > 0
-        int lo = -1, hi = -1;
-        auto coord = [&](int i) { return axis == 0 ? geom[i].cx : axis == 1 ? geom[i].cy : geom[i].cz; };
+    // screen never passes (r2 = -inf).
+    void scan_lists() {
         for (int i = 0; i < n; ++i) {
-            if (geom[i].shape != kPlaneX + axis) continue;
-            if (lo < 0 || coord(i) < coord(lo)) lo = i;
-            if (hi < 0 || coord(i) > coord(hi)) hi = i;
+            DGeom g = geom[i];
+            g.pad[0] = i;
+            if (g.shape == kSphere) {
+                scan_spheres.push_back(g);
+            } else if (g.shape != kRect) {
+                if (!in_slab[i]) scan_planes.push_back(g);
+            }
         }
-        if (lo < 0 || !(coord(lo) < coord(hi))) continue;
-        // |o_k| < big  =>  |c - o_k| < 2^40 (c_hi - c_lo) for both planes
-        const double big = std::ldexp(coord(hi) - coord(lo), 40) - std::max(std::fabs(coord(lo)), std::fabs(coord(hi)));
-        if (!(big > 0.0) || !std::isfinite(big)) continue;
-        D.slab_big[axis] = big;
-        D.slab_mask |= 1 << axis;
-        D.slab_lo[axis] = coord(lo);
-        D.slab_hi[axis] = coord(hi);
-        D.slab_ilo[axis] = lo;
-        D.slab_ihi[axis] = hi;
-        in_slab[lo] = in_slab[hi] = 1;
-    }
-    for (int i = 0; i < n; ++i) {
-        DGeom g = geom[i];
-        g.pad[0] = i;
-        if (g.shape == kSphere) {
+        n_planes = (int)scan_planes.size();
+    n_spheres = (int)scan_spheres.size();
+        if (n_spheres & 1) {
+            DGeom g;
+            memset(&g, 0, sizeof g);
+            g.nx = -1.0;  // radius^2 < 0: the exact test cannot pass either
+            g.fr2 = -INFINITY;
+            g.shape = kSphere;
+            g.pad[0] = -1;
             scan_spheres.push_back(g);
-        } else if (g.shape != kRect) {
-            if (!in_slab[i]) scan_planes.push_back(g);
+        }
+        // the origin-dependent term of every record for the origin (0,0,0) (see origin0_term)
+        auto put_term = [](DGeom& g, double v) {
+            uint64_t u;
+            memcpy(&u, &v, 8);
+            g.pad[1] = (int32_t)(uint32_t)u;
+            g.pad[2] = (int32_t)(uint32_t)(u >> 32);
+        };
+        for (DGeom& g : scan_planes) put_term(g, g.nx * (g.cx - 0.0) + g.ny * (g.cy - 0.0) + g.nz * (g.cz - 0.0));
+        for (DGeom& g : scan_spheres) {
+            const double dx = 0.0 - g.cx, dy = 0.0 - g.cy, dz = 0.0 - g.cz;
+            put_term(g, (dx * dx + dy * dy + dz * dz) - g.nx);
+        }
+        scan_screen.assign(scan_spheres.size() / 2, DScreen2());
+    scan_screen0.assign(scan_spheres.size() / 2, DScreen2());
+        for (size_t k = 0; k < scan_spheres.size(); ++k) {
+            const DGeom& g = scan_spheres[k];
+            DScreen2& r = scan_screen[k / 2];
+            r.cx[k & 1] = g.fcx;
+            r.cy[k & 1] = g.fcy;
+            r.cz[k & 1] = g.fcz;
+            r.r2[k & 1] = g.fr2;
+            DScreen2& r0 = scan_screen0[k / 2];
+            r0.cx[k & 1] = g.fcx;
+            r0.cy[k & 1] = g.fcy;
+            r0.cz[k & 1] = g.fcz;
+            // float c-term of the float centre, one rounding (the screen's error bound allows several)
+            r0.r2[k & 1] = (float)(((double)g.fcx * g.fcx + (double)g.fcy * g.fcy + (double)g.fcz * g.fcz) - (double)g.fr2);
         }
     }
-    const int n_planes = (int)scan_planes.size(), n_spheres = (int)scan_spheres.size();
-    if (n_spheres & 1) {
-        DGeom g;
-        memset(&g, 0, sizeof g);
-        g.nx = -1.0;  // radius^2 < 0: the exact test cannot pass either
-        g.fr2 = -INFINITY;
-        g.shape = kSphere;
-        g.pad[0] = -1;
-        scan_spheres.push_back(g);
-    }
-    // the origin-dependent term of every record for the origin (0,0,0) (see origin0_term)
-    auto put_term = [](DGeom& g, double v) {
-        uint64_t u;
-        memcpy(&u, &v, 8);
-        g.pad[1] = (int32_t)(uint32_t)u;
-        g.pad[2] = (int32_t)(uint32_t)(u >> 32);
-    };
-    for (DGeom& g : scan_planes) put_term(g, g.nx * (g.cx - 0.0) + g.ny * (g.cy - 0.0) + g.nz * (g.cz - 0.0));
-    for (DGeom& g : scan_spheres) {
-        const double dx = 0.0 - g.cx, dy = 0.0 - g.cy, dz = 0.0 - g.cz;
-        put_term(g, (dx * dx + dy * dy + dz * dz) - g.nx);
-    }
-    std::vector<DScreen2> scan_screen(scan_spheres.size() / 2), scan_screen0(scan_spheres.size() / 2);
-    for (size_t k = 0; k < scan_spheres.size(); ++k) {
-        const DGeom& g = scan_spheres[k];
-        DScreen2& r = scan_screen[k / 2];
-        r.cx[k & 1] = g.fcx;
-        r.cy[k & 1] = g.fcy;
-        r.cz[k & 1] = g.fcz;
-        r.r2[k & 1] = g.fr2;
-        DScreen2& r0 = scan_screen0[k / 2];
-        r0.cx[k & 1] = g.fcx;
-        r0.cy[k & 1] = g.fcy;
-        r0.cz[k & 1] = g.fcz;
-        // float c-term of the float centre, one rounding (the screen's error bound allows several)
-        r0.r2[k & 1] = (float)(((double)g.fcx * g.fcx + (double)g.fcy * g.fcy + (double)g.fcz * g.fcz) - (double)g.fr2);
-    }
+
     // Grouped layout of the LDS-tiled scan (wavefront pipeline): the spheres in groups of
     // kGroupBodies, ordered along a Morton curve so that a group is spatially compact.  Per group a
     // bounding sphere in float (centre, R^2 rounded outwards): a wave examines the members only when
     // some lane's ray might enter the bound.  Member records are the float (centre, r^2) pairs of
     // the per-body screen; slots past the end can never pass (r^2 = -inf).  grp_order maps member
     // slots to body indices.  (Planes are scanned from the plane list, as in the fused kernel.)
-    std::vector<int32_t> order;
-    {
-        std::vector<int> sph;
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int i = 0; i < n; ++i) {
-            if (geom[i].shape == kSphere) {
-                sph.push_back(i);
-                const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = std::min(lo[k], c[k]);
-                    hi[k] = std::max(hi[k], c[k]);
+    int sphere_groups() {
+        std::vector<int32_t> order;
+        {
+            std::vector<int> sph;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int i = 0; i < n; ++i) {
+                if (geom[i].shape == kSphere) {
+                    sph.push_back(i);
+                    const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
+                    for (int k = 0; k < 3; ++k) {
+                        lo[k] = std::min(lo[k], c[k]);
+                        hi[k] = std::max(hi[k], c[k]);
+                    }
                 }
             }
-        }
-        auto morton = [&](int i) {
-            const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
-            uint64_t code = 0;
-            uint32_t q[3];
-            for (int k = 0; k < 3; ++k) {
-                double u = hi[k] > lo[k] ? (c[k] - lo[k]) / (hi[k] - lo[k]) : 0.0;
-                if (!(u >= 0.0)) u = 0.0;  // also NaN
-                if (u > 1.0) u = 1.0;
-                q[k] = (uint32_t)(u * 1023.0);
+            auto morton = [&](int i) {
+                const double c[3] = {geom[i].cx, geom[i].cy, geom[i].cz};
+                uint64_t code = 0;
+                uint32_t q[3];
+                for (int k = 0; k < 3; ++k) {
+                    double u = hi[k] > lo[k] ? (c[k] - lo[k]) / (hi[k] - lo[k]) : 0.0;
+                    if (!(u >= 0.0)) u = 0.0;  // also NaN
+                    if (u > 1.0) u = 1.0;
+                    q[k] = (uint32_t)(u * 1023.0);
+                }
+                for (int bit = 9; bit >= 0; --bit)
+                    for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> bit) & 1u);
+                return code;
+            };
+            std::vector<std::pair<uint64_t, int>> keyed;
+            for (int i : sph) keyed.push_back({morton(i), i});
+            std::sort(keyed.begin(), keyed.end());
+            for (auto& kv : keyed) order.push_back(kv.second);
+            // whole pairs of super-groups (kSuperGroups groups each)
+            while (order.empty() || order.size() % (2 * kSuperGroups * kGroupBodies)) order.push_back(-1);
+            const int n_groups = (int)order.size() / kGroupBodies;
+            std::vector<DScreen2> members(order.size() / 2), bounds(n_groups / 2);
+            for (size_t k = 0; k < order.size(); ++k) {
+                DScreen2& r = members[k / 2];
+                const int i = order[k];
+                const bool sphere = i >= 0 && geom[i].shape == kSphere;
+                // non-spheres are always examined (an all-NaN record never screens out), padding never
+                const float other = i >= 0 ? std::nanf("") : 0.0f;
+                r.cx[k & 1] = sphere ? geom[i].fcx : other;
+                r.cy[k & 1] = sphere ? geom[i].fcy : other;
+                r.cz[k & 1] = sphere ? geom[i].fcz : other;
+                r.r2[k & 1] = sphere ? geom[i].fr2 : (i >= 0 ? std::nanf("") : -INFINITY);
             }
-            for (int bit = 9; bit >= 0; --bit)
-                for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> bit) & 1u);
-            return code;
-        };
-        std::vector<std::pair<uint64_t, int>> keyed;
-        for (int i : sph) keyed.push_back({morton(i), i});
-        std::sort(keyed.begin(), keyed.end());
-        for (auto& kv : keyed) order.push_back(kv.second);
-        // whole pairs of super-groups (kSuperGroups groups each)
-        while (order.empty() || order.size() % (2 * kSuperGroups * kGroupBodies)) order.push_back(-1);
-        const int n_groups = (int)order.size() / kGroupBodies;
-        std::vector<DScreen2> members(order.size() / 2), bounds(n_groups / 2);
-        for (size_t k = 0; k < order.size(); ++k) {
-            DScreen2& r = members[k / 2];
-            const int i = order[k];
-            const bool sphere = i >= 0 && geom[i].shape == kSphere;
-            // non-spheres are always examined (an all-NaN record never screens out), padding never
-            const float other = i >= 0 ? std::nanf("") : 0.0f;
-            r.cx[k & 1] = sphere ? geom[i].fcx : other;
-            r.cy[k & 1] = sphere ? geom[i].fcy : other;
-            r.cz[k & 1] = sphere ? geom[i].fcz : other;
-            r.r2[k & 1] = sphere ? geom[i].fr2 : (i >= 0 ? std::nanf("") : -INFINITY);
-        }
-        for (int g = 0; g < n_groups; ++g) {
-            DScreen2& r = bounds[g / 2];
-            double c[3] = {0.0, 0.0, 0.0};
-            int cnt = 0;
-            for (int k = 0; k < kGroupBodies; ++k) {
-                const int i = order[(size_t)g * kGroupBodies + k];
-                if (i < 0) continue;
-                c[0] += geom[i].cx;
-                c[1] += geom[i].cy;
-                c[2] += geom[i].cz;
-                cnt++;
-            }
-            float fc[3] = {0.0f, 0.0f, 0.0f};
-            float fr2 = -INFINITY;  // empty group: never entered
-            if (cnt > 0) {
-                for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
-                double R = 0.0;  // measured from the float centre actually stored
+            for (int g = 0; g < n_groups; ++g) {
+                DScreen2& r = bounds[g / 2];
+                double c[3] = {0.0, 0.0, 0.0};
+                int cnt = 0;
                 for (int k = 0; k < kGroupBodies; ++k) {
                     const int i = order[(size_t)g * kGroupBodies + k];
                     if (i < 0) continue;
-                    const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
-                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
+                    c[0] += geom[i].cx;
+                    c[1] += geom[i].cy;
+                    c[2] += geom[i].cz;
+                    cnt++;
                 }
-                fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
-                if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
-                c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
-                if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+                float fc[3] = {0.0f, 0.0f, 0.0f};
+                float fr2 = -INFINITY;  // empty group: never entered
+                if (cnt > 0) {
+                    for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
+                    double R = 0.0;  // measured from the float centre actually stored
+                    for (int k = 0; k < kGroupBodies; ++k) {
+                        const int i = order[(size_t)g * kGroupBodies + k];
+                        if (i < 0) continue;
+                        const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
+                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
+                    }
+                    fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
+                    if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
+                    c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
+                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+                }
+                r.cx[g & 1] = fc[0];
+                r.cy[g & 1] = fc[1];
+                r.cz[g & 1] = fc[2];
+                r.r2[g & 1] = fr2;
             }
-            r.cx[g & 1] = fc[0];
-            r.cy[g & 1] = fc[1];
-            r.cz[g & 1] = fc[2];
-            r.r2[g & 1] = fr2;
-        }
-        // second level: a bounding sphere around the bounds of kSuperGroups consecutive groups
-        const int n_super = n_groups / kSuperGroups;
-        std::vector<DScreen2> supers(n_super / 2);
-        for (int sg = 0; sg < n_super; ++sg) {
-            double c[3] = {0.0, 0.0, 0.0};
-            int cnt = 0;
-            for (int k = 0; k < kSuperGroups; ++k) {
-                const int g = sg * kSuperGroups + k;
-                const DScreen2& b = bounds[g / 2];
-                if (!(b.r2[g & 1] >= 0.0f)) continue;  // empty group
-                c[0] += b.cx[g & 1];
-                c[1] += b.cy[g & 1];
-                c[2] += b.cz[g & 1];
-                cnt++;
-            }
-            float fc[3] = {0.0f, 0.0f, 0.0f};
-            float fr2 = -INFINITY;
-            if (cnt > 0) {
-                for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
-                double R = 0.0;
+            // second level: a bounding sphere around the bounds of kSuperGroups consecutive groups
+            const int n_super = n_groups / kSuperGroups;
+            std::vector<DScreen2> supers(n_super / 2);
+            for (int sg = 0; sg < n_super; ++sg) {
+                double c[3] = {0.0, 0.0, 0.0};
+                int cnt = 0;
                 for (int k = 0; k < kSuperGroups; ++k) {
                     const int g = sg * kSuperGroups + k;
                     const DScreen2& b = bounds[g / 2];
-                    if (!(b.r2[g & 1] >= 0.0f)) continue;
-                    const double dx = (double)b.cx[g & 1] - fc[0], dy = (double)b.cy[g & 1] - fc[1], dz = (double)b.cz[g & 1] - fc[2];
-                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)b.r2[g & 1]));
+                    if (!(b.r2[g & 1] >= 0.0f)) continue;  // empty group
+                    c[0] += b.cx[g & 1];
+                    c[1] += b.cy[g & 1];
+                    c[2] += b.cz[g & 1];
+                    cnt++;
                 }
-                fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
-                if (!(fr2 >= 0.0f)) fr2 = INFINITY;
-                c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
-                if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+                float fc[3] = {0.0f, 0.0f, 0.0f};
+                float fr2 = -INFINITY;
+                if (cnt > 0) {
+                    for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
+                    double R = 0.0;
+                    for (int k = 0; k < kSuperGroups; ++k) {
+                        const int g = sg * kSuperGroups + k;
+                        const DScreen2& b = bounds[g / 2];
+                        if (!(b.r2[g & 1] >= 0.0f)) continue;
+                        const double dx = (double)b.cx[g & 1] - fc[0], dy = (double)b.cy[g & 1] - fc[1], dz = (double)b.cz[g & 1] - fc[2];
+                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)b.r2[g & 1]));
+                    }
+                    fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
+                    if (!(fr2 >= 0.0f)) fr2 = INFINITY;
+                    c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
+                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+                }
+                DScreen2& r = supers[sg / 2];
+                r.cx[sg & 1] = fc[0];
+                r.cy[sg & 1] = fc[1];
+                r.cz[sg & 1] = fc[2];
+                r.r2[sg & 1] = fr2;
             }
-            DScreen2& r = supers[sg / 2];
-            r.cx[sg & 1] = fc[0];
-            r.cy[sg & 1] = fc[1];
-            r.cz[sg & 1] = fc[2];
-            r.r2[sg & 1] = fr2;
+            int rcg;
+            if ((rcg = s->d_grp_supers.ensure(sizeof(DScreen2) * supers.size()))) return rcg;
+            HIP_TRY(hipMemcpy(s->d_grp_supers.p, supers.data(), sizeof(DScreen2) * supers.size(), hipMemcpyHostToDevice));
+            D.grp_supers = (const DScreen2*)s->d_grp_supers.p;
+            if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
+            if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
+            if ((rcg = s->d_grp_order.ensure(sizeof(int32_t) * order.size()))) return rcg;
+            HIP_TRY(hipMemcpy(s->d_grp_members.p, members.data(), sizeof(DScreen2) * members.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s->d_grp_bounds.p, bounds.data(), sizeof(DScreen2) * bounds.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s->d_grp_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+            D.grp_members = (const DScreen2*)s->d_grp_members.p;
+            D.grp_bounds = (const DScreen2*)s->d_grp_bounds.p;
+            D.grp_order = (const int32_t*)s->d_grp_order.p;
+            D.n_groups = n_groups;
+            for (int k = 0; k < 3; ++k) {  // box of the sphere centres (the whole scene when there are none)
+                const bool any = hi[k] > lo[k];
+                D.sort_mid[k] = any ? (float)(0.5 * (lo[k] + hi[k])) : 0.0f;
+                D.sort_inv[k] = any ? (float)(2.0 / (hi[k] - lo[k])) : 1.0f;
+            }
         }
-        int rcg;
-        if ((rcg = s->d_grp_supers.ensure(sizeof(DScreen2) * supers.size()))) return rcg;
-        HIP_TRY(hipMemcpy(s->d_grp_supers.p, supers.data(), sizeof(DScreen2) * supers.size(), hipMemcpyHostToDevice));
-        D.grp_supers = (const DScreen2*)s->d_grp_supers.p;
-        if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
-        if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
-        if ((rcg = s->d_grp_order.ensure(sizeof(int32_t) * order.size()))) return rcg;
-        HIP_TRY(hipMemcpy(s->d_grp_members.p, members.data(), sizeof(DScreen2) * members.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s->d_grp_bounds.p, bounds.data(), sizeof(DScreen2) * bounds.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s->d_grp_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
-        D.grp_members = (const DScreen2*)s->d_grp_members.p;
-        D.grp_bounds = (const DScreen2*)s->d_grp_bounds.p;
-        D.grp_order = (const int32_t*)s->d_grp_order.p;
-        D.n_groups = n_groups;
-        for (int k = 0; k < 3; ++k) {  // box of the sphere centres (the whole scene when there are none)
-            const bool any = hi[k] > lo[k];
-            D.sort_mid[k] = any ? (float)(0.5 * (lo[k] + hi[k])) : 0.0f;
-            D.sort_inv[k] = any ? (float)(2.0 / (hi[k] - lo[k])) : 1.0f;
+        return PT_OK;
+    }
+
+    // Device copies of the lists and the scalar fields of DScene.
+    int upload() {
+        if (scan_planes.empty()) scan_planes.resize(1);
+        if (scan_spheres.empty()) scan_spheres.resize(2);
+        if (scan_screen.empty()) scan_screen.resize(1);
+        if (scan_screen0.empty()) scan_screen0.resize(1);
+        int rc;
+        if ((rc = s->d_scan_planes.ensure(sizeof(DGeom) * scan_planes.size()))) return rc;
+        if ((rc = s->d_scan_spheres.ensure(sizeof(DGeom) * scan_spheres.size()))) return rc;
+        if ((rc = s->d_scan_screen.ensure(sizeof(DScreen2) * scan_screen.size()))) return rc;
+        if ((rc = s->d_scan_screen0.ensure(sizeof(DScreen2) * scan_screen0.size()))) return rc;
+        HIP_TRY(hipMemcpy(s->d_scan_planes.p, scan_planes.data(), sizeof(DGeom) * scan_planes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_scan_spheres.p, scan_spheres.data(), sizeof(DGeom) * scan_spheres.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_scan_screen.p, scan_screen.data(), sizeof(DScreen2) * scan_screen.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_scan_screen0.p, scan_screen0.data(), sizeof(DScreen2) * scan_screen0.size(), hipMemcpyHostToDevice));
+        if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
+        if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
+        if ((rc = s->d_lights.ensure(sizeof(int32_t) * std::max<size_t>(1, s->lights.size())))) return rc;
+        HIP_TRY(hipMemcpy(s->d_geom.p, geom.data(), sizeof(DGeom) * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_mat.p, mat.data(), sizeof(DMat) * n, hipMemcpyHostToDevice));
+        if (!s->lights.empty())
+            HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), sizeof(int32_t) * s->lights.size(), hipMemcpyHostToDevice));
+        D.geom = (const DGeom*)s->d_geom.p;
+        D.mat = (const DMat*)s->d_mat.p;
+        D.lights = (const int32_t*)s->d_lights.p;
+        D.scan_planes = (const DGeom*)s->d_scan_planes.p;
+        D.scan_spheres = (const DGeom*)s->d_scan_spheres.p;
+        D.scan_screen = (const DScreen2*)s->d_scan_screen.p;
+        D.scan_screen0 = (const DScreen2*)s->d_scan_screen0.p;
+        D.n_planes = n_planes;
+        D.n_spheres = n_spheres;
+        D.hit_eps = hit_eps;
+        D.n_rects = (int)rects.size();
+        if (!rects.empty()) {
+            int rcr = s->d_scan_rects.ensure(sizeof(DRect) * rects.size());
+            if (rcr) return rcr;
+            HIP_TRY(hipMemcpy(s->d_scan_rects.p, rects.data(), sizeof(DRect) * rects.size(), hipMemcpyHostToDevice));
+            D.scan_rects = (const DRect*)s->d_scan_rects.p;
         }
-    }
-    if (scan_planes.empty()) scan_planes.resize(1);
-    if (scan_spheres.empty()) scan_spheres.resize(2);
-    if (scan_screen.empty()) scan_screen.resize(1);
-    if (scan_screen0.empty()) scan_screen0.resize(1);
-    int rc;
-    if ((rc = s->d_scan_planes.ensure(sizeof(DGeom) * scan_planes.size()))) return rc;
-    if ((rc = s->d_scan_spheres.ensure(sizeof(DGeom) * scan_spheres.size()))) return rc;
-    if ((rc = s->d_scan_screen.ensure(sizeof(DScreen2) * scan_screen.size()))) return rc;
-    if ((rc = s->d_scan_screen0.ensure(sizeof(DScreen2) * scan_screen0.size()))) return rc;
-    HIP_TRY(hipMemcpy(s->d_scan_planes.p, scan_planes.data(), sizeof(DGeom) * scan_planes.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_scan_spheres.p, scan_spheres.data(), sizeof(DGeom) * scan_spheres.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_scan_screen.p, scan_screen.data(), sizeof(DScreen2) * scan_screen.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_scan_screen0.p, scan_screen0.data(), sizeof(DScreen2) * scan_screen0.size(), hipMemcpyHostToDevice));
-    if ((rc = s->d_geom.ensure(sizeof(DGeom) * n))) return rc;
-    if ((rc = s->d_mat.ensure(sizeof(DMat) * n))) return rc;
-    if ((rc = s->d_lights.ensure(sizeof(int32_t) * std::max<size_t>(1, s->lights.size())))) return rc;
-    HIP_TRY(hipMemcpy(s->d_geom.p, geom.data(), sizeof(DGeom) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_mat.p, mat.data(), sizeof(DMat) * n, hipMemcpyHostToDevice));
-    if (!s->lights.empty())
-        HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), sizeof(int32_t) * s->lights.size(), hipMemcpyHostToDevice));
-    D.geom = (const DGeom*)s->d_geom.p;
-    D.mat = (const DMat*)s->d_mat.p;
-    D.lights = (const int32_t*)s->d_lights.p;
-    D.scan_planes = (const DGeom*)s->d_scan_planes.p;
-    D.scan_spheres = (const DGeom*)s->d_scan_spheres.p;
-    D.scan_screen = (const DScreen2*)s->d_scan_screen.p;
-    D.scan_screen0 = (const DScreen2*)s->d_scan_screen0.p;
-    D.n_planes = n_planes;
-    D.n_spheres = n_spheres;
-    D.hit_eps = hit_eps;
-    D.n_rects = (int)rects.size();
-    if (!rects.empty()) {
-        int rcr = s->d_scan_rects.ensure(sizeof(DRect) * rects.size());
-        if (rcr) return rcr;
-        HIP_TRY(hipMemcpy(s->d_scan_rects.p, rects.data(), sizeof(DRect) * rects.size(), hipMemcpyHostToDevice));
-        D.scan_rects = (const DRect*)s->d_scan_rects.p;
-    }
-    if (s->has_measured) {
-        // Bin edges of the table indices (MatusikBRDF.h:211-257) as thresholds, descending:
-        // theta_half bin k starts at (k/90)^2 pi/2 and theta_diff bin k at k pi/180 (cosines),
-        // fi_diff bin k at k pi/180 (cotangents).  Entry 0 is never read; the padding is never reached.
-        std::vector<double> bins(kBinsTotal, -INFINITY);
-        const double half_pi = M_PI / 2.0;
-        for (int k = 1; k < 90; ++k) {
-            bins[kBinsHalf + k] = std::cos(((double)k * k / 8100.0) * half_pi);
-            bins[kBinsDiff + k] = std::cos((double)k * half_pi / 90.0);
+        if (s->has_measured) {
+            // Bin edges of the table indices (MatusikBRDF.h:211-257) as thresholds, descending:
+            // theta_half bin k starts at (k/90)^2 pi/2 and theta_diff bin k at k pi/180 (cosines),
+            // fi_diff bin k at k pi/180 (cotangents).  Entry 0 is never read; the padding is never reached.
+            std::vector<double> bins(kBinsTotal, -INFINITY);
+            const double half_pi = M_PI / 2.0;
+            for (int k = 1; k < 90; ++k) {
+                bins[kBinsHalf + k] = std::cos(((double)k * k / 8100.0) * half_pi);
+                bins[kBinsDiff + k] = std::cos((double)k * half_pi / 90.0);
+            }
+            for (int k = 1; k < 180; ++k) bins[kBinsPhi + k] = std::cos(k * M_PI / 180.0) / std::sin(k * M_PI / 180.0);
+            int rcb = s->d_brdf_bins.ensure(sizeof(double) * bins.size());
+            if (rcb) return rcb;
+            HIP_TRY(hipMemcpy(s->d_brdf_bins.p, bins.data(), sizeof(double) * bins.size(), hipMemcpyHostToDevice));
+            D.brdf_bins = (const double*)s->d_brdf_bins.p;
         }
-        for (int k = 1; k < 180; ++k) bins[kBinsPhi + k] = std::cos(k * M_PI / 180.0) / std::sin(k * M_PI / 180.0);
-        int rcb = s->d_brdf_bins.ensure(sizeof(double) * bins.size());
-        if (rcb) return rcb;
-        HIP_TRY(hipMemcpy(s->d_brdf_bins.p, bins.data(), sizeof(double) * bins.size(), hipMemcpyHostToDevice));
-        D.brdf_bins = (const double*)s->d_brdf_bins.p;
+        D.n_bodies = n;
+        D.sphere_c1max = c1max * 1.0001f;
+        D.sphere_r2max = r2max * 1.0001f;
+        D.n_lights = (int)s->lights.size();
+        D.width = s->width;
+        D.height = s->height;
+        D.estimator = s->estimator;
+        D.flags = s->flags;
+        return PT_OK;
     }
-    D.n_bodies = n;
-    D.sphere_c1max = c1max * 1.0001f;
-    D.sphere_r2max = r2max * 1.0001f;
-    D.n_lights = (int)s->lights.size();
-    D.width = s->width;
-    D.height = s->height;
-    D.estimator = s->estimator;
-    D.flags = s->flags;
+
     // The direct term of next-event estimation is dead for the whole scene when emission*colour of
     // every light is exactly zero and the flux it would be scaled by is finite for every material
     // (no measured tables, glass ior >= 1, finite colours); light indices must fit 7 bits.
     // flux of the direct term can only be finite-by-construction in a scene of finite, moderate numbers
-    bool moderate = true;
-    for (int i = 0; i < n; ++i) {
-        const pt_body& b = s->bodies[i];
-        auto ok = [](double v) { return std::isfinite(v) && std::fabs(v) < 1e100; };
+    void classify() {
+        bool moderate = true;
+        for (int i = 0; i < n; ++i) {
+            const pt_body& b = s->bodies[i];
+            auto ok = [](double v) { return std::isfinite(v) && std::fabs(v) < 1e100; };
+            for (int k = 0; k < 3; ++k)
+                moderate = moderate && ok(b.color[k]) && ok(b.emission[k]) && ok(b.center[k]) && ok(b.normal[k]);
+            moderate = moderate && ok(b.radius);
+        }
         for (int k = 0; k < 3; ++k)
-            moderate = moderate && ok(b.color[k]) && ok(b.emission[k]) && ok(b.center[k]) && ok(b.normal[k]);
-        moderate = moderate && ok(b.radius);
+            moderate = moderate && std::isfinite(s->camera.origin[k]) && std::isfinite(s->camera.topleft[k]) &&
+                       std::isfinite(s->camera.topright[k]) && std::isfinite(s->camera.bottomleft[k]);
+        D.flux_finite = moderate ? 1 : 0;
+        bool dead = s->estimator == PT_EST_NEE && s->lights.size() >= 2 && moderate;
+        for (int i = 0; i < n && dead; ++i) {
+            const pt_body& b = s->bodies[i];
+            if (b.material == PT_MEASURED) dead = false;
+            if (b.material == PT_GLASS && !(b.ior >= 1.0)) dead = false;
+        }
+        for (int li : s->lights)
+            for (int k = 0; k < 3; ++k) dead = dead && (s->bodies[li].emission[k] * s->bodies[li].color[k] == 0.0);
+        D.nee_emission_only = dead ? 1 : 0;
+        D.seed = s->seed;
+        for (int k = 0; k < 3; ++k) {
+            D.cam_o[k] = s->camera.origin[k];
+            D.cam_tl[k] = s->camera.topleft[k];
+            D.cam_xd[k] = s->camera.topright[k] - s->camera.topleft[k];
+            D.cam_yd[k] = s->camera.bottomleft[k] - s->camera.topleft[k];
+        }
     }
-    for (int k = 0; k < 3; ++k)
-        moderate = moderate && std::isfinite(s->camera.origin[k]) && std::isfinite(s->camera.topleft[k]) &&
-                   std::isfinite(s->camera.topright[k]) && std::isfinite(s->camera.bottomleft[k]);
-    D.flux_finite = moderate ? 1 : 0;
-    bool dead = s->estimator == PT_EST_NEE && s->lights.size() >= 2 && moderate;
-    for (int i = 0; i < n && dead; ++i) {
-        const pt_body& b = s->bodies[i];
-        if (b.material == PT_MEASURED) dead = false;
-        if (b.material == PT_GLASS && !(b.ior >= 1.0)) dead = false;
-    }
-    for (int li : s->lights)
-        for (int k = 0; k < 3; ++k) dead = dead && (s->bodies[li].emission[k] * s->bodies[li].color[k] == 0.0);
-    D.nee_emission_only = dead ? 1 : 0;
-    D.seed = s->seed;
-    for (int k = 0; k < 3; ++k) {
-        D.cam_o[k] = s->camera.origin[k];
-        D.cam_tl[k] = s->camera.topleft[k];
-        D.cam_xd[k] = s->camera.topright[k] - s->camera.topleft[k];
-        D.cam_yd[k] = s->camera.bottomleft[k] - s->camera.topleft[k];
-    }
-    return PT_OK;
-}
 
+    int run() {
+        body_records();
+        find_slabs();
+        scan_lists();
+        int rc = sphere_groups();
+        if (rc == PT_OK) rc = upload();
+        if (rc == PT_OK) classify();
+        return rc;
+    }
+};
+
+int upload_scene(pt_scene* s) { return SceneUpload(s).run(); }
 
 int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
