@@ -667,3 +667,23 @@ def test_overlapped_batches_equal_one_call_per_iteration():
         r.render_device(k, 1, single.data_ptr(), stream)
     torch.cuda.synchronize()
     assert torch.equal(whole.view(torch.int64), single.view(torch.int64))
+
+
+def test_4k_frame_partitions_and_full_width_strip(port):
+    """3840x2160 (the largest configured frame): eight tile partitions sum to the single-partition
+    frame bit for bit; a full-width strip of it equals the oracle."""
+    W, H = 3840, 2160
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=3))
+    whole = r.render(5, 2)
+    acc = np.zeros_like(whole)
+    for rank in range(8):
+        r.set_partition(rank, 8)
+        acc += r.render(5, 2)
+    assert same_bits(acc, whole)
+    r.close()
+    W, H = 3840, 6
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=3))
+    s = oracle_scene(port, r, W, H, 3)
+    want, _ = port.render(s, MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
+    r.close()
