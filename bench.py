@@ -180,7 +180,7 @@ def main():
     checksum = float(accum.sum().item()) / (W * H * 3 * IT)
     if rank == 0:
         out = {
-            "metric": "paths/sec (whole node), 1024x768 NEE",
+            "metric": "paths/sec (whole node), 1024x768 NEE, 1/2/4/8 GPUs; % of FP64 VALU peak",
             "value": paths / elapsed,
             "unit": "paths/s",
             "n_gpus": world,
