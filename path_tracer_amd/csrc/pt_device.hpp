@@ -400,7 +400,7 @@ PTD_INLINE bool scan_sphere_exact(const DGeom& g, V3 o, V3 d, double& t) {
     bool ok = (disc > 0.0) && (b < 0.0);
     if (__builtin_amdgcn_ballot_w64(ok) != 0) {
         double dd = disc;
-        asm volatile("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
+        asm("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
         t = -b - sqrt(dd);
     }
     return ok;
@@ -514,7 +514,7 @@ PTD_INLINE bool scan_sphere_exact_origin0(const DGeom& g, V3 d, double& t) {
     const bool ok = (disc > 0.0) && (b < 0.0);
     if (__builtin_amdgcn_ballot_w64(ok) != 0) {
         double dd = disc;
-        asm volatile("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
+        asm("" : "+v"(dd));  // keeps the square root inside this wave-uniform branch
         t = -b - sqrt(dd);
     }
     return ok;
@@ -1137,9 +1137,10 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
                 if ((need > g) & ((unsigned)q < 64u)) wave_slots[q] = (uint16_t)(lane | (g << 6) | (light << 9));
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // The slots are written and read by lanes of one wave: its LDS instructions execute in program
+        // order, and the compiler keeps the possibly aliasing store ahead of the load.  No fence, wave
+        // barrier or scheduling barrier here: the compiler takes each for a write to global memory,
+        // and every scene record load of the shadow scans below would become a vector load.
         bool lit = false;
         if (base + lane < total) {
             const unsigned slot = wave_slots[lane];
@@ -1157,7 +1158,6 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
             lit = hit == rec.body_of(g, owner);  // next_event.cpp:428-430
         }
         const lanemask lit_mask = PTD_MASK(lit);
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g = 0; g < kMaxDepth; ++g) {
             if (first[g + 1] > base && first[g] < base + 64) {
