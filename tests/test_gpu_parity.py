@@ -687,3 +687,39 @@ def test_4k_frame_partitions_and_full_width_strip(port):
     want, _ = port.render(s, MODE_PIXEL, 0, 3)
     assert same_bits(r.render(0, 3), want)
     r.close()
+
+
+def test_brdf_table_files(tmp_path):
+    """read_brdf (MatusikBRDF.h:84-108): a table file in the reference's format gives the lookups of
+    the uploaded table; wrong dimensions, short and missing files are reported, not fatal."""
+    r = pt.Renderer(pt.preset("nee15_measured", 8, 8, seed=1))
+    table = pt.synthetic_brdf_table(2)
+    path = str(tmp_path / "synthetic.binary")
+    pt.write_brdf_file(path, table)
+    r.brdf_upload(0, table)
+    r.brdf_load_file(1, path)
+    z = np.load(os.path.join(GOLDEN, "brdf.npz"))
+    a_rgb, a_ind = r.brdf_lookup(0, z["angles"])
+    b_rgb, b_ind = r.brdf_lookup(1, z["angles"])
+    assert np.array_equal(a_ind, b_ind) and same_bits(a_rgb, b_rgb)
+    # the value of an index: red, green and blue planes of the file, scaled (MatusikBRDF.h:68-72)
+    n = pt.BRDF_TABLE_DOUBLES // 3
+    i = int(a_ind[0])
+    want = np.array([table[i] * (1.0 / 1500.0), table[n + i] * (1.15 / 1500.0), table[2 * n + i] * (1.66 / 1500.0)])
+    if (want < 0).any():
+        want[:] = 0.0
+    assert same_bits(a_rgb[0], want)
+    bad = str(tmp_path / "bad_dims.binary")
+    with open(bad, "wb") as f:
+        np.array([90, 90, 181], dtype=np.int32).tofile(f)
+        table.tofile(f)
+    short = str(tmp_path / "short.binary")
+    with open(short, "wb") as f:
+        np.array([90, 90, 180], dtype=np.int32).tofile(f)
+        table[:1000].tofile(f)
+    for p in (bad, short, str(tmp_path / "missing.binary")):
+        with pytest.raises(pt.PtError):
+            r.brdf_load_file(2, p)
+    with pytest.raises(pt.PtError):
+        r.brdf_upload(9, table)
+    r.close()
