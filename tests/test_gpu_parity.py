@@ -723,3 +723,20 @@ def test_brdf_table_files(tmp_path):
     with pytest.raises(pt.PtError):
         r.brdf_upload(9, table)
     r.close()
+
+
+def test_renderer_mirror_iterate_and_save(port, tmp_path):
+    """The host mirror used the way worker() and main() use the reference class (main.cpp:436-442,
+    656): construct, iterate() n times, save() — buffer and PPM bytes equal the oracle's."""
+    W, H, n = 48, 32, 5
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=21))
+    for _ in range(n):
+        r.iterate()
+    s = oracle_scene(port, r, W, H, 21)
+    want, _ = port.render(s, MODE_PIXEL, 0, n)
+    assert r.iterations_done == n and same_bits(r.buffer, want)
+    out = str(tmp_path / "mirror.ppm")
+    r.save(out)
+    with open(out, "rb") as f:
+        assert f.read() == port.save_ppm(want, n, W, H)
+    r.close()
