@@ -82,8 +82,6 @@ PTOR_NOINST void ptor_rt_begin_iteration(uint32_t iteration) {
 }
 
 PTOR_NOINST long long ptor_rt_draws(void) { return g.draws; }
-static long long g_dbg[4];
-PTOR_NOINST void ptor_rt_debug(long long* o) { for (int i=0;i<4;i++) o[i]=g_dbg[i]; }
 
 PTOR_NOINST int __wrap_rand(void) {
     g.draws++;
@@ -118,13 +116,11 @@ PTOR_NOINST void __wrap_srand(unsigned) {}
 
 // -finstrument-functions hooks (only the hooked build of ref_harness.cpp emits calls).
 PTOR_NOINST void __cyg_profile_func_enter(void* fn, void*) {
-    g_dbg[0]++;
     if (g.mode != PTOR_MODE_PIXEL) return;
-    g_dbg[1]++;
     if (fn == g_addr_getray[0] || fn == g_addr_getray[1] || fn == g_addr_getray[2]) {
         // Camera::getRay is called exactly once per pixel, first thing in the pixel body.
         ptor_rng_init(&g.rng, g.seed, g.iteration, PTOR_DOM_PIXEL, g.pixel++);
-        g.in_pixel = true; g_dbg[2]++;
+        g.in_pixel = true;
     }
 }
 
@@ -132,7 +128,7 @@ PTOR_NOINST void __cyg_profile_func_exit(void* fn, void*) {
     if (g.mode != PTOR_MODE_PIXEL) return;
     if (fn == g_addr_iadd[0] || fn == g_addr_iadd[1] || fn == g_addr_iadd[2]) {
         // V3::iadd is called exactly once per pixel, last thing in the pixel body.
-        g.in_pixel = false; g_dbg[3]++;
+        g.in_pixel = false;
     }
 }
 
