@@ -107,3 +107,12 @@ def test_save_ppm_edge_values(tmp_path):
     with open(path, "rb") as f:
         data = f.read().decode()
     assert data == g["ppm"]["0"]["text"] == g["ppm"]["1"]["text"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/main.cpp"), reason="needs the reference checkout")
+def test_reference_side_binding_stub_compiles():
+    """The replacement body of worker() (main.cpp:436-458) that calls the C ABI compiles against the
+    reference's own classes and include/ptgpu.h (oracle/binding_stub_check.cpp)."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "binding-check"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
