@@ -740,3 +740,26 @@ def test_renderer_mirror_iterate_and_save(port, tmp_path):
     with open(out, "rb") as f:
         assert f.read() == port.save_ppm(want, n, W, H)
     r.close()
+
+
+def test_two_scenes_alive_at_once():
+    """Handles own their buffers and side streams: renders of two scenes queued on two torch streams
+    without synchronising in between equal their solo renders."""
+    import torch
+
+    W, H, IT = 256, 192, 40
+    ra = pt.Renderer(pt.preset("nee15", W, H, seed=5))
+    rb = pt.Renderer(pt.preset("main32", W, H, seed=6))
+    solo_a, solo_b = ra.render(0, IT), rb.render(0, IT)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ta = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    tb = torch.zeros_like(ta)
+    torch.cuda.synchronize()
+    for k in range(4):
+        ra.render_device(k * 10, 10, ta.data_ptr(), sa.cuda_stream)
+        rb.render_device(k * 10, 10, tb.data_ptr(), sb.cuda_stream)
+    torch.cuda.synchronize()
+    assert same_bits(ta.cpu().numpy().reshape(H, W, 3), solo_a)
+    assert same_bits(tb.cpu().numpy().reshape(H, W, 3), solo_b)
+    ra.close()
+    rb.close()
