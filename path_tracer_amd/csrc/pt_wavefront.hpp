@@ -134,7 +134,7 @@ PTD_INLINE void pending_eval(const DScene& S, Pending& pd, V3 o, V3 d, int skip,
             s.nx = g->nx;
             double t;
             const bool ok = scan_sphere_exact(s, o, d, t);
-            merge_hit(ok, t, idx, skip, 0.0, hit, mint);  // this pipeline is not used with a hit threshold
+            merge_hit(ok, t, idx, skip, S.hit_eps, hit, mint);
         }
     }
     pd.n = 0;
@@ -147,7 +147,16 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     const lanemask long_dir = PTD_MASK(!(fdx * fdx + fdy * fdy + fdz * fdz <= 1.000001f));
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    if (active) scan_all_planes<false>(S, S.scan_planes, o, d, skip, hit, mint);
+    if (active) {
+        scan_all_planes<false>(S, S.scan_planes, o, d, skip, hit, mint);
+        const DRect* __restrict__ rects = S.scan_rects;  // raytrace3.cpp's third shape, a short list
+        const int n_rects = S.n_rects;
+        for (int k = 0; k < n_rects; ++k) {
+            double t;
+            const bool ok = scan_rect(rects[k], o, d, t);
+            merge_hit(ok, t, rects[k].body, skip, S.hit_eps, hit, mint);
+        }
+    }
     Pending pd;
     pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
     pd.n = 0u;
@@ -489,6 +498,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_finish(DScene S, WfState W, dou
         L = mk(0.0, 0.0, 0.0);
         for (int k = W.nrec[p] - 1; k >= 0; --k) {
             DMat m = S.mat[W.bod[(size_t)k * W.cap + p]];
+            if (S.flags & 2u) L = add(L, mk(0.0, 0.0, 0.0));  // raytrace3.cpp:840, see trace_path
             L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
         }
     } else {

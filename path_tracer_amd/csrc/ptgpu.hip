@@ -1204,8 +1204,6 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const bool use_wavefront = s->pipeline == PT_PIPELINE_WAVEFRONT ||
                                (s->pipeline == PT_PIPELINE_AUTO && (int)s->bodies.size() > kMaxBodiesFused);
-    if (use_wavefront && (s->has_rectangles || (s->flags & PT_F_RAYTRACE3)))
-        return fail(PT_ERR_UNSUPPORTED, "rectangles and the raytrace3 hit threshold need the fused pipeline (at most 127 bodies)");
     if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
     const int batch = use_wavefront ? s->wf_batch : s->batch;

@@ -25,12 +25,15 @@ for seed in range(first, last):
     s = T.oracle_scene(port, r, W, H, seed, flags=pt.F_RAYTRACE3)
     want, _ = port.render(s, MODE_PIXEL, 0, 3)
     got = r.render(0, 3)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    got_wf = r.render(0, 3)
+    r.set_pipeline(pt.PIPELINE_FUSED)
     rng = np.random.default_rng(seed)
     rays = np.concatenate([rng.uniform([-1.9, -2.5, -0.5], [1.9, 4.5, 2.5], (3000, 3)),
                            rng.normal(size=(3000, 3)) * rng.uniform(0.05, 4.0, (3000, 1))], axis=1)
     t_all, idx, t = port.intersect(s, rays)
     gi, gt = r.intersect_batch(rays)
-    nf = int((got.view(np.uint64) != want.view(np.uint64)).sum())
+    nf = int((got.view(np.uint64) != want.view(np.uint64)).sum()) + int((got_wf.view(np.uint64) != want.view(np.uint64)).sum())
     nr = int((gi != idx).sum()) + int((r.intersect_all(rays).view(np.uint64) != t_all.view(np.uint64)).sum())
     if nf or nr:
         bad.append((seed, nf, nr))

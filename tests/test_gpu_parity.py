@@ -629,11 +629,26 @@ def test_rectangles_need_the_path_tracing_estimator():
     d.estimator = pt.EST_NEE
     with pytest.raises(pt.PtError):
         pt.Renderer(d)
-    d = rectangle_scene(1, 16, 16)
+
+
+@pytest.mark.parametrize("seed", [3, 14, 25])
+def test_rectangles_in_the_wavefront_pipeline(port, seed):
+    """Rectangles and the 1e-7 hit threshold in the large-scene pipeline: forced on a small scene it
+    equals the fused kernel and the oracle; with 150 extra spheres it is selected by itself."""
+    W, H = 36, 24
+    d = rectangle_scene(seed, W, H, n_rect=6, n_sphere=5, n_plane=2)
     r = pt.Renderer(d)
+    s = oracle_scene(port, r, W, H, seed, flags=pt.F_RAYTRACE3)
+    want, _ = port.render(s, MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
     r.set_pipeline(pt.PIPELINE_WAVEFRONT)
-    with pytest.raises(pt.PtError):
-        r.render(0, 1)
+    assert same_bits(r.render(0, 3), want)
+    r.close()
+    d = rectangle_scene(seed, W, H, n_rect=6, n_sphere=150, n_plane=2)
+    r = pt.Renderer(d)
+    s = oracle_scene(port, r, W, H, seed, flags=pt.F_RAYTRACE3)
+    want, _ = port.render(s, MODE_PIXEL, 0, 2)
+    assert same_bits(r.render(0, 2), want)
     r.close()
 
 
