@@ -778,3 +778,35 @@ def test_two_scenes_alive_at_once():
     assert same_bits(tb.cpu().numpy().reshape(H, W, 3), solo_b)
     ra.close()
     rb.close()
+
+
+def test_degenerate_rectangles(port):
+    """Rectangles with coincident or collinear corners (the constructor normalises zero vectors:
+    NaN normal or NaN edge directions), a huge and a tiny one: every intersect value, the nearest
+    hits and the frames equal the oracle's (which never hits the NaN ones, like the reference)."""
+    W, H = 30, 20
+    d = rectangle_scene(5, W, H, n_rect=6, n_sphere=3, n_plane=1)
+    cases = [
+        [0.0, 2.0, 0.0] * 4,                                                    # a point
+        [-1.0, 2.0, 0.0, 1.0, 2.0, 0.0, 2.0, 2.0, 0.0, 3.0, 2.0, 0.0],          # collinear corners
+        [-1.0, 3.0, 0.0, -1.0, 3.0, 0.0, 1.0, 3.0, 1.0, -1.0, 3.0, 1.0],        # p1 == p2
+        [-1e9, 4.0, -1e9, 1e9, 4.0, -1e9, 1e9, 4.0, 1e9, -1e9, 4.0, 1e9],       # huge
+        [0.0, 1.5, 0.0, 1e-9, 1.5, 0.0, 1e-9, 1.5, 1e-9, 0.0, 1.5, 1e-9],       # tiny
+    ]
+    for k, c in enumerate(cases):
+        for q in range(12):
+            d.bodies[k].corners[q] = c[q]
+    r = pt.Renderer(d)
+    s = oracle_scene(port, r, W, H, 5, flags=pt.F_RAYTRACE3)
+    want, _ = port.render(s, MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    assert same_bits(r.render(0, 3), want)
+    rng = np.random.default_rng(8)
+    rays = np.concatenate([rng.uniform([-1.9, -2.5, -0.5], [1.9, 4.5, 2.5], (3000, 3)),
+                           rng.normal(size=(3000, 3)) * rng.uniform(0.1, 3.0, (3000, 1))], axis=1)
+    t_all, idx, t = port.intersect(s, rays)
+    assert same_bits(r.intersect_all(rays), t_all)
+    gi, gt = r.intersect_batch(rays)
+    assert np.array_equal(gi, idx) and same_bits(gt[idx >= 0], t[idx >= 0])
+    r.close()
