@@ -1,5 +1,5 @@
 """One-off: the headline resolution against the oracle, bit for bit (a few minutes of CPU).
-    python scripts/full_frame_check.py [iterations] [scene]"""
+    python scripts/full_frame_check.py [iterations] [scene] [width height]"""
 import os
 import sys
 import time
@@ -16,10 +16,10 @@ from _oracle import MODE_PIXEL  # noqa: E402
 
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 scene = sys.argv[2] if len(sys.argv) > 2 else "nee15"
-W, H = 1024, 768
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1024, 768)
 port = _oracle.Port()
 r = pt.Renderer(pt.preset(scene, W, H, seed=1))
-s = T.oracle_scene(port, r, W, H, 1)
+s = T.oracle_scene(port, r, W, H, 1, flags=r.desc.flags)
 first = 7200 - n_it  # the last iterations of the headline render
 t0 = time.time()
 want, _ = port.render(s, MODE_PIXEL, first, n_it)
