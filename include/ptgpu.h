@@ -191,7 +191,8 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
 
 /* Statistics of the last pt_render* call on this handle. */
 typedef struct pt_stats {
-    double paths;          /* (pixel, iteration) samples traced */
+    double paths;          /* (pixel, iteration) samples: in-image destination pixels of this handle's partition
+                              times iterations */
     double kernel_ms;      /* device time of the estimator kernels (HIP events) */
     double launches;       /* estimator kernel launches */
 } pt_stats;

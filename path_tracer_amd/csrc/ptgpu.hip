@@ -1126,7 +1126,7 @@ int pt_scene_destroy(pt_scene* s) {
 }
 
 int pt_scene_bodies(const pt_scene* s, pt_body* out, int cap) {
-    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (!s || (!out && cap > 0)) return fail(PT_ERR_INVALID, "pt_scene_bodies: null argument");
     int n = (int)s->bodies.size();
     for (int i = 0; i < n && i < cap; ++i) out[i] = s->bodies[i];
     return n;
@@ -1272,7 +1272,15 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamWaitEvent(st, s->ev_acc[(nbatch - 1) & 1], 0));
-    s->last_paths = (double)n_iterations * (double)J;  // upper bound: includes out-of-image lanes of edge tiles
+    // destination pixels of this partition inside the image, times iterations (a short frame leaves up
+    // to W + H of its last slots without a sample; those few are counted all the same)
+    double owned_pixels = 0;
+    for (int q = 0; q < P.owned_tiles; ++q) {
+        const int tile = q * P.world + P.rank;
+        const int x0 = (tile % P.tiles_x) * P.tile_w, y0 = (tile / P.tiles_x) * P.tile_h;
+        owned_pixels += (double)std::max(0, std::min(P.tile_w, W - x0)) * (double)std::max(0, std::min(P.tile_h, H - y0));
+    }
+    s->last_paths = (double)n_iterations * owned_pixels;
     return PT_OK;
 }
 
