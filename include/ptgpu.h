@@ -139,6 +139,20 @@ int pt_render(pt_scene* scene, int first_iteration, int n_iterations, double* ac
  * them; renders of different scenes are independent. */
 int pt_render_device(pt_scene* scene, int first_iteration, int n_iterations, double* accum_dev, void* stream);
 
+/* pt_render_device for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same
+ * arguments and the same bits in accum_dev as pt_render_device; the frame tables and the batch's
+ * samples live in a fixed device array of PT_NOALLOC_SCRATCH_BYTES that the library holds on every
+ * GPU it runs on (its address is resolved once per device, when a scene is created there), every
+ * kernel is queued on `stream`, and the call makes no hipMalloc/hipFree and creates no stream or
+ * event.  Limits: the fused pipeline only (at most 127 bodies, PT_ERR_UNSUPPORTED otherwise), and
+ * one iteration of the partition's tables and samples must fit the scratch (about 26 bytes per
+ * pixel: a 2 560 000-pixel frame; larger frames return PT_ERR_UNSUPPORTED).  All calls on one GPU
+ * share that GPU's array, from whatever scene: two such calls that overlap in time on one GPU race;
+ * queue them on one stream or synchronise between them.  pt_get_stats does not cover these calls. */
+#define PT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int pt_render_device_noalloc(pt_scene* scene, int first_iteration, int n_iterations, double* accum_dev, void* stream);
+
 /* Nearest-hit scan (main.cpp:372-383) over a ray batch: rays6[n][6] = origin, direction.
  * `skip` is a body index excluded from the scan (the light in next_event.cpp:415-419) or -1.
  * idx[i] = -1 and t[i] = DBL_MAX on a miss.  Host pointers. */

@@ -202,6 +202,14 @@ class Renderer:
             )
         )
 
+    def render_device_noalloc(self, first_iteration, n_iterations, accum_ptr, stream_ptr=0):
+        """pt_render_device_noalloc: same result, work buffers in the library's fixed device scratch."""
+        _check(
+            lib().pt_render_device_noalloc(
+                self._h, int(first_iteration), int(n_iterations), C.c_void_p(accum_ptr), C.c_void_p(stream_ptr)
+            )
+        )
+
     def set_partition(self, rank, world, tile_w=32, tile_h=8):
         _check(lib().pt_set_partition(self._h, rank, world, tile_w, tile_h))
 

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -399,10 +400,37 @@ struct Tmp {
     operator T*() const { return p; }
 };
 
+// ---- fixed device scratch of pt_render_device_noalloc ----------------------------------------
+// One array per GPU the library's code object is loaded on, held until the process ends.  In host
+// code the array's name is only a handle: the address a kernel can use comes from
+// hipGetSymbolAddress, asked once per device (with that device current) and kept here.
+constexpr size_t kScratchBytes = (size_t)PT_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on `device`, which must be the current device.
+int scratch_address(int device, void** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(PT_ERR_INVALID, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(PT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return PT_OK;
+}
+
 }  // namespace
 
 struct pt_scene {
     int device = 0;
+    void* scratch_ptr = nullptr;  // this device's copy of the file-scope scratch array
     int width = 0, height = 0, estimator = 0;
     uint32_t flags = 0;
     uint64_t seed = 0;
@@ -1038,6 +1066,10 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
         delete s;
         return fail(PT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     }
+    if (int rcs = scratch_address(s->device, &s->scratch_ptr)) {
+        delete s;
+        return rcs;
+    }
     s->width = desc->width;
     s->height = desc->height;
     s->estimator = desc->estimator;
@@ -1295,6 +1327,65 @@ int pt_render(pt_scene* s, int first_iteration, int n_iterations, double* accum_
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(accum_host, s->d_accum.p, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// The fused pipeline with every work buffer carved out of the device's fixed scratch array and every
+// kernel queued on the caller's stream, batch after batch: no hipMalloc / hipFree, no stream or
+// event creation.  Nothing in the scratch has to start at zero: k_frame_layout writes every table
+// entry that is read afterwards and k_trace writes every sample slot.
+int pt_render_device_noalloc(pt_scene* s, int first_iteration, int n_iterations, double* accum_dev, void* stream_) {
+    if (!s || !accum_dev) return fail(PT_ERR_INVALID, "pt_render_device_noalloc: null argument");
+    if (n_iterations < 0 || first_iteration < 0) return fail(PT_ERR_INVALID, "pt_render_device_noalloc: negative iteration range");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = check_measured_tables(s);
+    if (rc) return rc;
+    if ((int)s->bodies.size() > kMaxBodiesFused || s->pipeline == PT_PIPELINE_WAVEFRONT)
+        return fail(PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: fused pipeline only (at most 127 bodies)");
+    hipStream_t st = (hipStream_t)stream_;
+    const Partition P = s->part;
+    if (P.owned_tiles == 0 || n_iterations == 0) return PT_OK;
+    const int W = s->width, H = s->height;
+    const size_t J = (size_t)P.owned_tiles * kBlock;
+    const size_t CK = (size_t)(W + kXStride - 1) / kXStride;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // bytes of one iteration's tables and samples, each array 256-byte aligned for any batch size
+    const size_t per_it = (size_t)H * CK * 8 + (size_t)H * 8 + (size_t)(H + 1) * 4 + 4 + 3 * J * 8;
+    const size_t slack = 5 * 256;
+    if (per_it + slack > kScratchBytes)
+        return fail(PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: one iteration of this frame needs " + std::to_string(per_it + slack) +
+                                            " bytes of work buffers, the fixed scratch holds " + std::to_string(kScratchBytes));
+    const int batch = (int)std::min<size_t>((size_t)std::max(1, s->batch), (kScratchBytes - slack) / per_it);
+    unsigned char* base = (unsigned char*)s->scratch_ptr;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        void* p = base + off;
+        off += up(bytes);
+        return p;
+    };
+    double* xs = (double*)carve((size_t)batch * H * CK * 8);
+    double* ys = (double*)carve((size_t)batch * H * 8);
+    int32_t* rs = (int32_t*)carve((size_t)batch * (H + 1) * 4);
+    int32_t* npix = (int32_t*)carve((size_t)batch * 4);
+    double* samples = (double*)carve((size_t)batch * 3 * J * 8);
+    if (off > kScratchBytes) return fail(PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: work buffers exceed the fixed scratch");
+    const int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
+    for (int it0 = first_iteration, left = n_iterations; left > 0; it0 += batch, left -= batch) {
+        const int B = std::min(batch, left);
+        hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, st, s->seed, W, H, it0, s->xstep, s->ystep, xs, ys,
+                           rs, npix);
+        dim3 grid(P.owned_tiles, B);
+        if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
+            hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        else if (s->estimator == PT_EST_NEE && s->has_measured)
+            hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        else if (s->estimator == PT_EST_NEE)
+            hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        else
+            hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, st, P, W, H, B, npix, samples, J, accum_dev);
+        HIP_TRY(hipGetLastError());
+    }
     return PT_OK;
 }
 
