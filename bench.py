@@ -1,13 +1,21 @@
-"""Headline benchmark: paths/s of the NEE estimator, 1024x768 at 7200 iterations (the reference's
-path_tracing_1024x768x7200i workload), on N GPUs of one node.
+"""Benchmark of the estimator on N GPUs of one node: paths/s, roofline of the dominant kernel, the
+CPU partner timed beside it.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py                                  # headline: --config C2, --gpus 1
+    python bench.py --config C3|C4|C5                # the other configured workloads at their full sizes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Configured workloads (all seed 1, synthetic data):
+    C2  next_event.cpp's 15-body scene, 1024x768, 7200 iterations (the path_tracing_1024x768x7200i run)
+    C3  the same scene with bodies 0, 1, 6, 7 on measured-BRDF tables (four synthetic MERL-format
+        tables: the .binary blobs are not available), 1024x768, 7200 iterations
+    C4  the 15-body scene at 3840x2160, 4096 iterations
+    C5  the 15-body room + 9985 spheres (10 000 bodies), 1024x768, 1024 iterations (wavefront pipeline)
+
 A step is one complete render of the workload into a zeroed FP64 accumulator resident in HBM:
-every rank renders its interleaved 32x8 destination tiles, then one RCCL all-reduce (sum) of the
-W*H*3 FP64 accumulators makes the whole frame available on every rank.  Rank 0 prints one JSON line.
+every rank renders its interleaved 32x8 destination tiles, then the owned tiles are exchanged with
+one RCCL all-gather so that every rank holds the whole frame.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -21,64 +29,112 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flop
 
+CONFIGS = {
+    "C2": dict(scene="nee15", width=1024, height=768, iterations=7200),
+    "C3": dict(scene="nee15_measured", width=1024, height=768, iterations=7200),
+    "C4": dict(scene="nee15", width=3840, height=2160, iterations=4096),
+    "C5": dict(scene="synthetic10k", width=1024, height=768, iterations=1024),
+}
 
-def traffic_bytes_per_launch(paths_per_launch):
-    """HBM bytes per launch of the estimator kernel from the committed PMC passes (FETCH_SIZE x 2 +
-    WRITE_SIZE, per path), scaled to this run's launch size; None when no such measurement exists."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+
+def pmc_summary(scene):
+    """Per-path figures of the estimator kernel from the committed counter passes
+    (scripts/pmc.sh -> profiles/pmc_summary.json), or None when this scene has none."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)["bytes_per_path"] * paths_per_launch
+        return json.load(f).get(scene)
 
 
-def cpu_baseline(width, height, seconds_target):
-    """The CPU partner timed on this host's cores: the reference's own Renderer::iterate()
-    (oracle/_ref) when that build is present, else the C restatement.  Bounded sample."""
+def host_cores():
+    """Cores this process may use: the affinity mask, cut to the cgroup CPU quota and to
+    OMP_NUM_THREADS when those are set (a GPU box hands each job a share of a larger machine)."""
+    info = {"host_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    cores = info["affinity"]
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            info["cgroup_cpu_quota"] = float(quota) / float(period)
+            cores = min(cores, max(1, int(info["cgroup_cpu_quota"])))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        info["omp_num_threads"] = int(os.environ["OMP_NUM_THREADS"])
+        cores = min(cores, max(1, info["omp_num_threads"]))
+    info["cores"] = max(1, cores)
+    return info
+
+
+def oracle_scene_of(port, desc, width, height, tables):
+    """The CPU restatement's scene for a preset (bodies as the constructors store them)."""
+    import ctypes
+
+    import _oracle
+    import path_tracer_amd as pt
+
+    stored = (_oracle.Body * desc.body_count)()
+    for i in range(desc.body_count):
+        tmp = pt.Body.from_buffer_copy(desc.bodies[i])
+        pt.lib().pt_body_construct(ctypes.byref(tmp))
+        for f, _ in _oracle.Body._fields_:
+            setattr(stored[i], f, getattr(tmp, "reserved" if f == "pad" else f))
+    cam = _oracle.Camera()
+    for f in ("origin", "topleft", "topright", "bottomleft"):
+        for k in range(3):
+            getattr(cam, f)[k] = getattr(desc.camera, f)[k]
+    return port.scene(stored, desc.body_count, cam, width, height, desc.estimator, seed=1, flags=desc.flags,
+                      tables=tables)
+
+
+def cpu_baseline(desc, scene_name, width, height, tables, seconds_target):
+    """The CPU partner on this host's cores, one independent single-thread worker per core (own
+    random stream each, which is what the per-thread rand() of the reference's platform gives).
+    The reference's own Renderer::iterate() (oracle/_ref) for its hard-coded 15-body scene when
+    that build is present, else the C restatement (oracle/cpu_ref.c).  Bounded sample: the frame is
+    shrunk (same scene, same camera) until one iteration per worker fits the time budget."""
     import _oracle
 
-    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
-    paths_per_it = width * height
-    est_rate = 0.6e6 * cores  # paths/s (the reference does about 0.6-0.7 M paths/s per core), to size the sample
-    iters = max(1, int(seconds_target * est_rate / (paths_per_it * cores)))
+    info = host_cores()
+    cores = info["cores"]
+    use_ref = scene_name == "nee15" and _oracle.Ref.available()
+    per_core = 0.65e6 if desc.body_count < 100 else 0.65e6 * 15.0 / desc.body_count  # paths/s, to size the sample
+    w, h = width, height
+    while w * h > 64 and w * h / per_core > seconds_target:
+        w, h = max(8, w // 2), max(8, h // 2)
+    iters = max(1, int(seconds_target * per_core / (w * h)))
     one_core = None
-    if _oracle.Ref.available():
+    if use_ref:
         ref = _oracle.Ref()
-        secs, _ = ref.time_iterate(1, width, height, iters, cores, seed=1)
+        secs, _ = ref.time_iterate(1, w, h, iters, cores, seed=1)
         kind = "reference"
         one_it = max(1, iters // 4)
-        secs1, _ = ref.time_iterate(1, width, height, one_it, 1, seed=1)
-        one_core = float(paths_per_it) * one_it / secs1
+        secs1, _ = ref.time_iterate(1, w, h, one_it, 1, seed=1)
+        one_core = float(w * h) * one_it / secs1
     else:
-        import ctypes
-
-        import path_tracer_amd as pt
-
         port = _oracle.Port()
-        d = pt.preset("nee15", width, height)
-        stored = (_oracle.Body * d.body_count)()
-        for i in range(d.body_count):
-            tmp = pt.Body.from_buffer_copy(d.bodies[i])
-            pt.lib().pt_body_construct(ctypes.byref(tmp))
-            for f, _ in _oracle.Body._fields_:
-                setattr(stored[i], f, getattr(tmp, "reserved" if f == "pad" else f))
-        cam = _oracle.Camera()
-        for f in ("origin", "topleft", "topright", "bottomleft"):
-            for k in range(3):
-                getattr(cam, f)[k] = getattr(d.camera, f)[k]
-        s = port.scene(stored, d.body_count, cam, width, height, _oracle.EST_NEE, seed=1)
+        s = oracle_scene_of(port, desc, w, h, tables)
         secs, _ = port.time_render(s, iters, cores)
         kind = "port"
-    paths = float(paths_per_it) * iters * cores
-    return {
+        one_it = max(1, iters // 4)
+        secs1, _ = port.time_render(s, one_it, 1)
+        one_core = float(w * h) * one_it / secs1
+    paths = float(w * h) * iters * cores
+    out = {
         "value": paths / secs,
         "unit": "paths/s",
         "cores": cores,
         "kind": kind,
         "one_core_value": one_core,
-        "sample": f"next_event 15-body scene {width}x{height}, {iters} iteration(s) on each of {cores} "
-                  f"independent single-thread workers ({paths:.3g} paths, {secs:.1f} s)",
+        "rng": "wrapped xoshiro128+ (the build's stream contract; cheaper than glibc rand(), which also takes a lock)",
+        "sample": f"{scene_name} scene {w}x{h}, {iters} iteration(s) on each of {cores} independent "
+                  f"single-thread workers ({paths:.3g} paths, {secs:.1f} s)",
     }
+    out.update({k: v for k, v in info.items() if k != "cores"})
+    # what the whole machine would do if every core of it ran a worker at the one-core rate
+    out["all_host_cores_extrapolated"] = one_core * info["host_cpu_count"]
+    return out
 
 
 def main():
@@ -86,14 +142,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=768)
-    ap.add_argument("--iterations", type=int, default=7200)
-    ap.add_argument("--scene", default="nee15")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--iterations", type=int, default=0)
+    ap.add_argument("--scene", default="")
     ap.add_argument("--pipeline", default="", choices=["", "fused", "wavefront"])
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.scene:
+        cfg["scene"] = args.scene
+    for k in ("width", "height", "iterations"):
+        if getattr(args, k):
+            cfg[k] = getattr(args, k)
+    as_configured = cfg == CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -118,13 +183,16 @@ def main():
         torch.cuda.set_device(local_rank)
     pt.set_device(local_rank)
 
-    W, H, IT = args.width, args.height, args.iterations
-    desc = pt.preset(args.scene, W, H, seed=1)
+    W, H, IT, scene = cfg["width"], cfg["height"], cfg["iterations"], cfg["scene"]
+    desc = pt.preset(scene, W, H, seed=1)
     r = pt.Renderer(desc)
-    n_measured = 0
+    tables = []
     for k in sorted({desc.bodies[i].brdf_id for i in range(desc.body_count) if desc.bodies[i].material == pt.MEASURED}):
-        r.brdf_upload(k, pt.synthetic_brdf_table(k))  # the MERL .binary blobs are not available: synthetic tables
-        n_measured += 1
+        while len(tables) <= k:
+            tables.append(None)
+        tables[k] = pt.synthetic_brdf_table(k)  # the MERL .binary blobs are not available: synthetic tables
+        r.brdf_upload(k, tables[k])
+    n_measured = sum(t is not None for t in tables)
     if args.pipeline:
         r.set_pipeline({"fused": pt.PIPELINE_FUSED, "wavefront": pt.PIPELINE_WAVEFRONT}[args.pipeline])
     # algorithmic work per path: 14 flop per plane test, 19 per sphere test, 56 per rectangle test
@@ -146,10 +214,11 @@ def main():
         "k_trace<NEE>" if desc.estimator == pt.EST_NEE else "k_trace<PT>")
     accum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    exchange = ptdist.Exchange(r, world, accum.device) if args.exchange == "gather" else None
 
     def step():
         accum.zero_()
-        ptdist.render_distributed(r, 0, IT, accum, rank, world, stream)
+        ptdist.render_distributed(r, 0, IT, accum, rank, world, stream, exchange=exchange)
 
     def fence():
         torch.cuda.synchronize()
@@ -193,12 +262,14 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} scene ({desc.body_count} bodies), {W}x{H}, {IT} iterations (spp), seed 1",
+                "workload": f"{args.config if as_configured else 'custom'}: {scene} scene ({desc.body_count} bodies), "
+                            f"{W}x{H}, {IT} iterations (spp), seed 1",
                 "rays_per_path": rays_per_path,
                 "rays_per_s": rays_per_path * paths / elapsed,
                 "bodies": desc.body_count,
                 "measured_brdf_tables": n_measured,
-                "partition": f"interleaved 32x8 tiles over {world} GPU(s) + RCCL all-reduce of FP64 accumulators",
+                "partition": f"interleaved 32x8 tiles over {world} GPU(s), RCCL "
+                             + ("all-gather of the owned tiles" if exchange else "all-reduce of the FP64 accumulators"),
                 "mean_radiance": checksum,
             },
         }
@@ -206,6 +277,7 @@ def main():
             paths_per_launch = traced / launches  # rank 0's own launches: a per-GPU figure when N > 1
             avg_ms = kernel_ms / launches
             achieved = paths_per_launch * flop_per_path / (avg_ms * 1e-3) / 1e12
+            pmc = pmc_summary(scene)
             out["roofline"] = {
                 "bound": "valu_fp64",
                 "achieved": achieved,
@@ -213,7 +285,11 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                 "frac_of_no_fma_ceiling": achieved / (FP64_VALU_PEAK_TFLOPS / 2),
-                "traffic": traffic_bytes_per_launch(paths_per_launch),
+                "traffic": pmc["bytes_per_path"] * paths_per_launch if pmc and pmc.get("bytes_per_path") else None,
+                "note": "algorithmic: every body test of every scan the reference makes, priced at its FP64 cost "
+                        "(14 flop per plane, 19 per sphere); the kernels answer many of them with FP32 screens, "
+                        "slabs, bounding groups or by proving a shadow scan dead, so this is a brute-force-equivalent "
+                        "rate and may exceed what the FP64 units execute (see `executed`)",
                 "hbm_view": {
                     "algorithmic_GBps": paths_per_launch * 24.0 / (avg_ms * 1e-3) / 1e9,
                     "peak_GBps": 8000.0,
@@ -222,20 +298,28 @@ def main():
                 "kernel": kernel_name,
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
+                "paths_per_launch": paths_per_launch,
                 "flop_per_path": flop_per_path,
             }
+            if pmc and pmc.get("fp64_flop_per_path"):
+                # what the FP64 units really executed (counter passes of the same kernel), at this run's rate
+                rate = paths_per_launch / (avg_ms * 1e-3)
+                ex = rate * pmc["fp64_flop_per_path"] / 1e12
+                out["roofline"]["executed"] = {
+                    "fp64_TFLOPs": ex,
+                    "frac_of_peak": ex / FP64_VALU_PEAK_TFLOPS,
+                    "fp64_share_of_valu_issue": pmc.get("fp64_share_of_valu_issue"),
+                    "valu_instructions_per_path": pmc.get("valu_insts_per_path"),
+                    "active_lanes_of_64": pmc.get("active_lanes"),
+                    "source": pmc.get("source"),
+                }
             if world > 1:
-                out["roofline"]["note"] = "rank 0's kernel launches; per-GPU rate"
-            if wavefront:
-                out["roofline"]["frac"] = None
-                out["roofline"]["frac_of_no_fma_ceiling"] = None
-                out["roofline"]["note"] = ("brute-force-equivalent rate: every body test of the reference's scans is "
-                                           "priced in FP64, while the grouped scan proves most of them misses with "
-                                           "bounding-sphere and FP32 screens, so this is not what the FP64 units execute")
+                out["roofline"]["note"] += "; rank 0's kernel launches, per-GPU rate"
             if world == 1 and not args.no_cpu:
-                cb = cpu_baseline(W, H, args.cpu_seconds)
+                cb = cpu_baseline(desc, scene, W, H, [t for t in tables] if tables else None, args.cpu_seconds)
                 out["cpu_baseline"] = cb
                 out["config"]["gpu_over_cpu"] = out["value"] / cb["value"]
+                out["config"]["gpu_over_cpu_all_host_cores_extrapolated"] = out["value"] / cb["all_host_cores_extrapolated"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

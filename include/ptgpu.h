@@ -118,6 +118,22 @@ int pt_brdf_load_file(pt_scene* scene, int brdf_id, const char* path);
  * (main.cpp:436-458, 642-645). */
 int pt_set_partition(pt_scene* scene, int rank, int world, int tile_w, int tile_h);
 
+/* The exchange step of a multi-GPU render, in place of the mutex-guarded sum of worker()
+ * (main.cpp:444-457): destination tiles are disjoint, so the ranks gather each other's owned tiles
+ * instead of summing whole frames.  Exchange layout of a partition: its owned tiles in order, a tile
+ * as 256 pixels row-major within the tile, a pixel as three doubles; pixels of edge tiles outside
+ * the image are zero.
+ *   pt_tiles_per_rank: ceil(tile count / world), the tile capacity every rank's packed buffer needs.
+ *   pt_tiles_pack:     accum_dev (W*H*3) -> packed_dev (tiles_capacity*768 doubles) for this handle's
+ *                      partition; tiles beyond the owned count are zero-filled.
+ *   pt_tiles_unpack:   gathered_dev (world * tiles_per_rank * 768 doubles, rank-major: the result of
+ *                      an all-gather of the packed buffers) -> every pixel of accum_dev.
+ * Device pointers; the kernels are queued on `stream`. */
+int pt_tiles_per_rank(const pt_scene* scene, int world);
+int pt_tiles_pack(pt_scene* scene, const double* accum_dev, double* packed_dev, int tiles_capacity, void* stream);
+int pt_tiles_unpack(pt_scene* scene, int world, int tiles_per_rank, const double* gathered_dev, double* accum_dev,
+                    void* stream);
+
 /* Two device pipelines compute the same estimator with identical results.  FUSED: one kernel per
  * batch, path state in registers/LDS, body list read through the scalar cache (up to 127 bodies).
  * WAVEFRONT: one kernel per stage over compacted queues of live paths, path state in HBM, body

@@ -213,6 +213,17 @@ class Renderer:
     def set_partition(self, rank, world, tile_w=32, tile_h=8):
         _check(lib().pt_set_partition(self._h, rank, world, tile_w, tile_h))
 
+    def tiles_per_rank(self, world):
+        return _check(lib().pt_tiles_per_rank(self._h, int(world)))
+
+    def tiles_pack(self, accum_ptr, packed_ptr, tiles_capacity, stream_ptr=0):
+        _check(lib().pt_tiles_pack(self._h, C.c_void_p(accum_ptr), C.c_void_p(packed_ptr), int(tiles_capacity),
+                                   C.c_void_p(stream_ptr)))
+
+    def tiles_unpack(self, world, tiles_per_rank, gathered_ptr, accum_ptr, stream_ptr=0):
+        _check(lib().pt_tiles_unpack(self._h, int(world), int(tiles_per_rank), C.c_void_p(gathered_ptr),
+                                     C.c_void_p(accum_ptr), C.c_void_p(stream_ptr)))
+
     def set_pipeline(self, pipeline):
         _check(lib().pt_set_pipeline(self._h, int(pipeline)))
 

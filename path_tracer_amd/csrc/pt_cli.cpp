@@ -13,12 +13,17 @@
 // still divides by the requested total.
 //
 // Extra options, after the four positionals: --seed N (default: time, like srand(time(NULL))),
-// --gpu ID, --out PATH, --literal-height (next_event only: height = argv[1] as
+// --gpu ID, --gpus N (render every worker's iterations on N GPUs of this node: interleaved
+// destination tiles per GPU and one RCCL gather, through libptnode.so, which is loaded only then;
+// the frame is the same bit for bit), --out PATH, --literal-height (next_event only: height = argv[1] as
 // next_event.cpp:596 literally does), --quiet, and --progressive: the output loop the reference
 // keeps commented out (main.cpp:614-640): rounds of min(10, max(remaining / T, 1)) iterations per
 // worker, the image saved after every round with the iterations done so far as sample count
 // (main: output_<done>.ppm, next_event: output.ppm rewritten), "Iterations between output: n" on
 // stdout.
+#include <dlfcn.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +33,39 @@
 #include <vector>
 
 #include "../../include/ptgpu.h"
+#include "../../include/ptgpu_node.h"
+
+namespace {
+
+// The node library sits next to libptgpu.so, one directory above this executable.
+struct NodeApi {
+    void* so = nullptr;
+    decltype(&pt_node_create) create = nullptr;
+    decltype(&pt_node_destroy) destroy = nullptr;
+    decltype(&pt_node_render) render = nullptr;
+    decltype(&pt_node_last_error) last_error = nullptr;
+    bool load() {
+        char exe[4096];
+        ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+        if (n <= 0) return false;
+        exe[n] = 0;
+        std::string dir(exe);
+        dir = dir.substr(0, dir.find_last_of('/'));  // .../bin
+        dir = dir.substr(0, dir.find_last_of('/'));  // package directory
+        so = dlopen((dir + "/libptnode.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!so) {
+            fprintf(stderr, "ptgpu: cannot load libptnode.so: %s\n", dlerror());
+            return false;
+        }
+        create = (decltype(create))dlsym(so, "pt_node_create");
+        destroy = (decltype(destroy))dlsym(so, "pt_node_destroy");
+        render = (decltype(render))dlsym(so, "pt_node_render");
+        last_error = (decltype(last_error))dlsym(so, "pt_node_last_error");
+        return create && destroy && render && last_error;
+    }
+};
+
+}  // namespace
 
 int main(int argc, const char* argv[]) {
     if (argc < 5) {
@@ -39,13 +77,14 @@ int main(int argc, const char* argv[]) {
     int iterations = (int)strtol(argv[3], NULL, 10);
     int thread_count = (int)strtol(argv[4], NULL, 10);
     uint64_t seed = (uint64_t)time(NULL);
-    int gpu = 0;
+    int gpu = 0, gpus = 0;
     bool quiet = false, progressive = false;
     std::string out;
     for (int i = 5; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], NULL, 10);
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else if (a == "--quiet") quiet = true;
         else if (a == "--progressive") progressive = true;
@@ -85,10 +124,31 @@ int main(int argc, const char* argv[]) {
         return 1;
     }
     pt_scene* scene = NULL;
-    if (pt_scene_create(&desc, &scene) != PT_OK) {
+    pt_node* node = NULL;
+    NodeApi api;
+    if (gpus >= 1) {
+        if (!api.load()) return 1;
+        std::vector<int> devices(gpus);
+        for (int d = 0; d < gpus; ++d) devices[d] = gpu + d;
+        if (api.create(&desc, devices.data(), gpus, &node) != PT_OK) {
+            fprintf(stderr, "ptgpu: %s\n", api.last_error());
+            return 1;
+        }
+    } else if (pt_scene_create(&desc, &scene) != PT_OK) {
         fprintf(stderr, "ptgpu: %s\n", pt_last_error());
         return 1;
     }
+    // one render call of either form: adds iterations [first, first + count) into dst
+    auto render = [&](int first, int count, double* dst) -> bool {
+        if (node) {
+            if (api.render(node, first, count, dst) == PT_OK) return true;
+            fprintf(stderr, "ptgpu: %s\n", api.last_error());
+            return false;
+        }
+        if (pt_render(scene, first, count, dst) == PT_OK) return true;
+        fprintf(stderr, "ptgpu: %s\n", pt_last_error());
+        return false;
+    };
     size_t n = (size_t)width * height * 3;
     std::vector<double> buffer(n, 0.0), priv;
     auto t0 = std::chrono::steady_clock::now();
@@ -104,10 +164,7 @@ int main(int argc, const char* argv[]) {
             printf("Iterations between output: %d\n", iteration_step);
             for (int k = 0; k < thread_count; ++k) {
                 priv.assign(n, 0.0);
-                if (pt_render(scene, next_iteration, iteration_step, priv.data()) != PT_OK) {
-                    fprintf(stderr, "ptgpu: %s\n", pt_last_error());
-                    return 1;
-                }
+                if (!render(next_iteration, iteration_step, priv.data())) return 1;
                 for (size_t i = 0; i < n; ++i) buffer[i] += priv[i];
                 next_iteration += iteration_step;
                 iterations_remaining -= iteration_step;
@@ -132,10 +189,7 @@ int main(int argc, const char* argv[]) {
                 priv.assign(n, 0.0);
                 dst = priv.data();
             }
-            if (pt_render(scene, k * per_worker, per_worker, dst) != PT_OK) {
-                fprintf(stderr, "ptgpu: %s\n", pt_last_error());
-                return 1;
-            }
+            if (!render(k * per_worker, per_worker, dst)) return 1;
             if (thread_count > 1)
                 for (size_t i = 0; i < n; ++i) buffer[i] += priv[i];
         }
@@ -151,6 +205,7 @@ int main(int argc, const char* argv[]) {
     printf("saving to file \"%s\"\n", out.c_str());  // main.cpp:413
 #endif
     int rc = pt_save_ppm(buffer.data(), iterations, width, height, out.c_str());
+    if (node) api.destroy(node);
     pt_scene_destroy(scene);
     if (rc != PT_OK) {
         fprintf(stderr, "cannot write %s\n", out.c_str());

@@ -254,6 +254,36 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(Partition P, int W, int H
     a[2] = az;
 }
 
+// ---- tile exchange -----------------------------------------------------------------------
+// The exchange layout of a partition: its owned tiles one after the other, a tile as 256 pixels in
+// row-major order within the tile, a pixel as its three FP64 channels: packed[(q*256 + tid)*3 + c].
+// Pixels of an edge tile outside the image are zero.  blockIdx.y selects the source rank of a
+// gathered buffer (rank-major, tiles_per_rank tiles each).
+__global__ void __launch_bounds__(kBlock) k_tiles_pack(Partition P, int W, int H, int tiles_capacity,
+                                                       const double* __restrict__ accum, double* __restrict__ packed) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int slot = q < P.owned_tiles ? slot_of(P, q, tid, W, H) : -1;
+    double* o = packed + ((size_t)q * kBlock + tid) * 3;
+    const double* a = accum + (size_t)max(slot, 0) * 3;
+    o[0] = slot >= 0 ? a[0] : 0.0;
+    o[1] = slot >= 0 ? a[1] : 0.0;
+    o[2] = slot >= 0 ? a[2] : 0.0;
+}
+__global__ void __launch_bounds__(kBlock) k_tiles_unpack(Partition P, int W, int H, int tiles_per_rank,
+                                                         const double* __restrict__ gathered, double* __restrict__ accum) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    P.rank = blockIdx.y;
+    const int total = P.tiles_x * P.tiles_y;
+    if (q * P.world + P.rank >= total) return;
+    const int slot = slot_of(P, q, tid, W, H);
+    if (slot < 0) return;
+    const double* g = gathered + (((size_t)P.rank * tiles_per_rank + q) * kBlock + tid) * 3;
+    double* a = accum + (size_t)slot * 3;
+    a[0] = g[0];
+    a[1] = g[1];
+    a[2] = g[2];
+}
+
 // ---- test / diagnostic kernels ---------------------------------------------------------------
 __global__ void k_intersect_batch(DScene S, const double* __restrict__ rays6, int n, int skip,
                                   int32_t* __restrict__ idx, double* __restrict__ t) {
@@ -1209,6 +1239,39 @@ int pt_brdf_load_file(pt_scene* s, int id, const char* path) {
 int pt_set_partition(pt_scene* s, int rank, int world, int tile_w, int tile_h) {
     if (!s) return fail(PT_ERR_INVALID, "null scene");
     return setup_partition(s, rank, world, tile_w, tile_h);
+}
+
+int pt_tiles_per_rank(const pt_scene* s, int world) {
+    if (!s || world < 1) return fail(PT_ERR_INVALID, "pt_tiles_per_rank: bad argument");
+    const int total = s->part.tiles_x * s->part.tiles_y;
+    return (total + world - 1) / world;
+}
+
+int pt_tiles_pack(pt_scene* s, const double* accum_dev, double* packed_dev, int tiles_capacity, void* stream) {
+    if (!s || !accum_dev || !packed_dev) return fail(PT_ERR_INVALID, "pt_tiles_pack: null argument");
+    if (tiles_capacity < s->part.owned_tiles) return fail(PT_ERR_INVALID, "pt_tiles_pack: capacity below the owned tile count");
+    if (tiles_capacity == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipLaunchKernelGGL(k_tiles_pack, dim3(tiles_capacity), dim3(kBlock), 0, (hipStream_t)stream, s->part, s->width, s->height,
+                       tiles_capacity, accum_dev, packed_dev);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_tiles_unpack(pt_scene* s, int world, int tiles_per_rank, const double* gathered_dev, double* accum_dev, void* stream) {
+    if (!s || !gathered_dev || !accum_dev || world < 1) return fail(PT_ERR_INVALID, "pt_tiles_unpack: bad argument");
+    Partition P = s->part;
+    if (world != P.world) {  // the layout of `world` ranks with this handle's tile shape
+        P.world = world;
+        P.rank = 0;
+    }
+    const int total = P.tiles_x * P.tiles_y;
+    if (tiles_per_rank < (total + world - 1) / world) return fail(PT_ERR_INVALID, "pt_tiles_unpack: tiles_per_rank too small");
+    HIP_TRY(hipSetDevice(s->device));
+    hipLaunchKernelGGL(k_tiles_unpack, dim3((total + world - 1) / world, world), dim3(kBlock), 0, (hipStream_t)stream, P,
+                       s->width, s->height, tiles_per_rank, gathered_dev, accum_dev);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
 }
 
 int pt_set_pipeline(pt_scene* s, int pipeline) {

@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_device_first(request):
+    """GPU runs: bring up torch's device context before the first ptgpu call and before any test
+    starts a child process on the GPU.  torch ships its own copy of the HIP runtime; bench.py and
+    the multi-GPU launchers initialise it first, so the tests do the same, once, at a defined point
+    instead of in the middle of the session."""
+    if any(item.get_closest_marker("gpu") for item in request.session.items):
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+            torch.cuda.synchronize()
+    yield
+
+
 @pytest.fixture(scope="session")
 def port():
     """The plain-C restatement (oracle/cpu_ref.c); built on demand where gcc is present."""

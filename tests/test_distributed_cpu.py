@@ -36,8 +36,15 @@ def _worker(rank, world, port, W, H, frame_path, out_path):
     part = np.where(ptd.owned_mask(W, H, rank, world)[:, :, None], frame, 0.0)
     accum = torch.from_numpy(part.reshape(-1).copy())
     ptd.all_reduce_accumulator(accum)
+    # the tile exchange: pack the owned tiles, all-gather, unpack (host mirrors of pt_tiles_pack/unpack)
+    packed = torch.from_numpy(ptd.pack_tiles_host(part, rank, world).reshape(-1).copy())
+    gathered = torch.zeros(world * packed.numel(), dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, packed)
+    T = ptd.tiles_per_rank(W, H, world)
+    whole = ptd.unpack_tiles_host(gathered.numpy().reshape(world, T, ptd.TILE_PIXELS, 3), W, H, world)
     if rank == 0:
         np.save(out_path, accum.numpy().reshape(H, W, 3))
+        np.save(out_path + ".gather.npy", whole)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,4 +63,6 @@ def test_two_ranks_reproduce_the_whole_frame(port, golden_scene, tmp_path):
     sock.close()
     mp.spawn(_worker, args=(2, free_port, W, H, frame_path, out_path), nprocs=2, join=True)
     got = np.load(out_path)
+    assert np.array_equal(got.view(np.uint64), frame.view(np.uint64))
+    got = np.load(out_path + ".gather.npy")
     assert np.array_equal(got.view(np.uint64), frame.view(np.uint64))

@@ -359,6 +359,37 @@ def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
         r.close()
 
 
+def test_drop_in_executable_on_a_node(port, tmp_path):
+    """`next_event W H iters threads --gpus 1`: the same render through libptnode.so — per-device
+    scenes, tile partition, RCCL gather of the owned tiles — gives the same PPM bytes."""
+    import subprocess
+
+    from conftest import ROOT
+
+    W, H, iters, threads = 70, 37, 6, 2  # partial edge tiles in both directions
+    exe = os.path.join(ROOT, "path_tracer_amd", "bin", "next_event")
+    outs = []
+    for extra in ([], ["--gpus", "1"]):
+        out = str(tmp_path / f"node{len(extra)}.ppm")
+        subprocess.run([exe, str(W), str(H), str(iters), str(threads), "--seed", "9", "--out", out, "--quiet"] + extra,
+                       check=True, timeout=120)
+        with open(out, "rb") as f:
+            outs.append(f.read())
+    assert outs[0] == outs[1]
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=9))
+    s = oracle_scene(port, r, W, H, 9)
+    per = iters // threads
+    total = np.zeros((H, W, 3))
+    for k in range(threads):
+        priv, _ = port.render(s, MODE_PIXEL, k * per, per)
+        total = total + priv
+    assert outs[1] == port.save_ppm(total, iters, W, H)
+    r.close()
+    bad = subprocess.run([exe, "16", "16", "1", "1", "--gpus", "99", "--quiet", "--out", str(tmp_path / "x.ppm")],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "does not exist" in bad.stderr
+
+
 def edge_rays(rng, n):
     """Origins inside, outside, exactly on and astronomically far from the walls; directions with
     exact zeros, negative zeros and components below the parallel threshold."""
@@ -666,6 +697,84 @@ def test_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "mismatching entries 0 " in out.stdout
+
+
+# Converged anchors of the reference itself: its unmodified iterate() with glibc rand(), srand(1),
+# 256x192 at 64 samples per pixel (mean radiance per channel, then the four image quadrants).
+ANCHORS = {
+    "nee15": dict(mean=(0.6039, 0.5014, 0.4825), TL=(0.6011, 0.4769, 0.3590), TR=(0.6279, 0.5570, 0.6307),
+                  BL=(0.5993, 0.4782, 0.4504), BR=(0.5873, 0.4933, 0.4898)),
+    "main32": dict(mean=(0.6519, 0.5092, 0.5251), TL=(0.8110, 0.5490, 0.5053), TR=(0.6191, 0.5376, 0.6451),
+                   BL=(0.6076, 0.4777, 0.4576), BR=(0.5698, 0.4724, 0.4923)),
+}
+
+
+@pytest.mark.parametrize("name", ["nee15", "main32"])
+def test_converged_image_statistics_match_the_reference_run(name):
+    """Independent random streams cannot agree per pixel, but region means must: the GPU render at the
+    anchors' size and sample count, against the reference's own run with its own rand().  The standard
+    error comes from the spread of eight 8-iteration sub-renders; both runs carry it, hence sqrt(2)."""
+    W, H, groups, per = 256, 192, 8, 8
+    r = pt.Renderer(pt.preset(name, W, H, seed=1))
+    subs = np.stack([r.render(g * per, per) / per for g in range(groups)])  # (8, H, W, 3)
+    r.close()
+    regions = dict(mean=(slice(0, H), slice(0, W)), TL=(slice(0, H // 2), slice(0, W // 2)),
+                   TR=(slice(0, H // 2), slice(W // 2, W)), BL=(slice(H // 2, H), slice(0, W // 2)),
+                   BR=(slice(H // 2, H), slice(W // 2, W)))
+    for key, (ys, xs) in regions.items():
+        m = subs[:, ys, xs, :].mean(axis=(1, 2))  # (8, 3) region means of the sub-renders
+        mean = m.mean(axis=0)
+        se = m.std(axis=0, ddof=1) / np.sqrt(groups)
+        tol = 4.0 * np.sqrt(2.0) * se + 5e-5  # + the rounding of the four-digit anchors
+        want = np.array(ANCHORS[name][key])
+        assert (np.abs(mean - want) < tol).all(), (name, key, mean, want, tol)
+        assert (tol < 0.02).all()  # the test has teeth: a percent-level bias would fail
+
+
+def test_rccl_exchange_with_one_rank():
+    """The multi-GPU exchange through RCCL itself: backend nccl, one rank on cuda:0; the all-gather of
+    the owned tiles and the all-reduce of the FP64 accumulator are really issued (no single-rank
+    shortcut) and the frame equals the plain render bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTGPU_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "rehearse_ranks.py"), "40"], env=env,
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "backend nccl" in out.stdout and "mismatching entries 0 " in out.stdout and "gather equals reduce True" in out.stdout
+
+
+def test_tile_exchange_layout_matches_host_mirror():
+    """pt_tiles_pack / pt_tiles_unpack against the numpy mirror in path_tracer_amd.distributed, on a frame
+    with partial edge tiles: pack per rank, concatenate as an all-gather would, unpack."""
+    import torch
+
+    from path_tracer_amd import distributed as ptdist
+
+    W, H = 100, 37
+    rng = np.random.default_rng(4)
+    frame = rng.normal(size=(H, W, 3))
+    dev = torch.from_numpy(frame.reshape(-1)).cuda()
+    for world in (1, 2, 3, 8):
+        r = pt.Renderer(pt.preset("nee15", W, H, seed=1))
+        T = r.tiles_per_rank(world)
+        assert T == ptdist.tiles_per_rank(W, H, world)
+        gathered = torch.full((world, T, 256, 3), -7.0, dtype=torch.float64, device="cuda")
+        for rank in range(world):
+            r.set_partition(rank, world)
+            r.tiles_pack(dev.data_ptr(), gathered[rank].data_ptr(), T)
+            torch.cuda.synchronize()
+            assert same_bits(gathered[rank].cpu().numpy(), ptdist.pack_tiles_host(frame, rank, world))
+        out = torch.zeros_like(dev)
+        r.tiles_unpack(world, T, gathered.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        assert same_bits(out.cpu().numpy().reshape(H, W, 3), frame)
+        assert same_bits(ptdist.unpack_tiles_host(gathered.cpu().numpy(), W, H, world), frame)
+        with pytest.raises(pt.PtError):
+            r.tiles_pack(dev.data_ptr(), gathered.data_ptr(), 0 if world > 1 else -1)
+        r.close()
 
 
 def test_overlapped_batches_equal_one_call_per_iteration():

@@ -22,6 +22,15 @@ def test_library_exports_every_declared_symbol():
     L = pt.lib()
     for name in declared:
         assert hasattr(L, name), f"libptgpu.so does not export {name}"
+    # the node library (several GPUs from one process): checked from its symbol table, without loading
+    # it here (it links RCCL, and this process may already hold torch's own copy of that library)
+    with open(os.path.join(ROOT, "include", "ptgpu_node.h")) as f:
+        node_declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(pt_node_[a-z_0-9]+)\s*\(", f.read(), flags=re.M))
+    assert len(node_declared) == 5
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "path_tracer_amd", "libptnode.so")],
+                        capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if " T " in line}
+    assert node_declared <= exported, node_declared - exported
 
 
 @pytest.mark.parametrize("name", ["main32", "nee15"])
