@@ -1137,10 +1137,12 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
                 if ((need > g) & ((unsigned)q < 64u)) wave_slots[q] = (uint16_t)(lane | (g << 6) | (light << 9));
             }
         }
-        // The slots are written and read by lanes of one wave: its LDS instructions execute in program
-        // order, and the compiler keeps the possibly aliasing store ahead of the load.  No fence, wave
-        // barrier or scheduling barrier here: the compiler takes each for a write to global memory,
-        // and every scene record load of the shadow scans below would become a vector load.
+        // The slots are written and read by lanes of one wave, whose LDS instructions execute in
+        // program order; the fence pair (wavefront scope, LDS address space only) makes that order part
+        // of the program: the stores above may not sink below it nor the loads below rise above it.
+        // Being confined to LDS it leaves the scene record loads of the shadow scans scalar loads.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         bool lit = false;
         if (base + lane < total) {
             const unsigned slot = wave_slots[lane];
