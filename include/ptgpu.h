@@ -183,6 +183,11 @@ int pt_intersect_all(pt_scene* scene, const double* rays6, int n, double* t_all)
 int pt_trace_paths(pt_scene* scene, const int32_t* it_idx2, const double* xy, int n, double* rgb, int32_t* nrec,
                    int32_t* bodies, double* points, int32_t* visible, int32_t* used);
 
+/* Diagnostics for the measured-material term: for the same n explicit samples as pt_trace_paths, the
+ * table index (MatusikBRDF.h:63-66) of every lit vertex that lies on a PT_MEASURED body, ind[n][5],
+ * -1 elsewhere.  Next-event scenes with a measured body only. */
+int pt_trace_brdf_indices(pt_scene* scene, const int32_t* it_idx2, const double* xy, int n, int32_t* ind);
+
 /* Frame geometry of one iteration (main.cpp:352-357): ys[H], xs[H*W], row_len[H]; *nrows rows. */
 int pt_frame_layout(pt_scene* scene, int iteration, double* ys, double* xs, int32_t* row_len, int32_t* nrows);
 

@@ -434,6 +434,8 @@ static lightlist find_lights(const por_scene* s) {
 }
 
 /* Pixel body of next_event.cpp:384-470.  `recs`/`nrec_out` (optional) expose the gather path. */
+static int* g_brdf_ind_out; /* diagnostics: table index of each lit measured vertex (see por_trace_brdf_indices) */
+
 static v3 radiance_nee(const por_scene* s, const cam* c, const lightlist* lights, draws* d, double x, double y,
                        hitrec* recs_out, int* nrec_out, int* visible_out) {
     v3 o = c->origin;
@@ -473,7 +475,9 @@ static v3 radiance_nee(const por_scene* s, const cam* c, const lightlist* lights
             double ti, pi_, to, po, r, g, b;
             vector_to_spherical(bdir, &ti, &pi_);
             vector_to_spherical(nprime, &to, &po);
-            brdf_lookup(s->brdf_tables[hb->brdf_id], ti, pi_, to, po, &r, &g, &b, NULL);
+            int ind;
+            brdf_lookup(s->brdf_tables[hb->brdf_id], ti, pi_, to, po, &r, &g, &b, &ind);
+            if (g_brdf_ind_out) g_brdf_ind_out[gi] = ind;
             final_color = add(mul(add(final_color, mul(lterm, V(r, g, b))), ld3(hb->color)), ld3(hb->emission));
         } else {
             v3 light_brdf = bounce(hb, d, bdir, nprime);
@@ -694,6 +698,23 @@ void por_rng_fill(uint64_t seed, uint32_t it, uint32_t dom, uint32_t idx, int n,
 }
 
 /* MatusikBRDF lookups on an in-memory table (3*1458000 doubles). */
+/* Diagnostics (single-threaded): the table index of every lit measured vertex of n explicit samples,
+ * ind[n][5], -1 where vertex gi is not a lit measured one. */
+void por_trace_brdf_indices(const por_scene* s, const int* it_idx2, const double* xy, int n, int* ind) {
+    cam c = make_cam(&s->camera);
+    lightlist lights = find_lights(s);
+    for (int k = 0; k < n; k++) {
+        draws d;
+        memset(&d, 0, sizeof d);
+        d.mode = PTOR_MODE_PIXEL;
+        stream(&d, s, (uint32_t)it_idx2[2 * k], PTOR_DOM_PIXEL, (uint32_t)it_idx2[2 * k + 1]);
+        for (int j = 0; j < POR_MAX_DEPTH; j++) ind[5 * k + j] = -1;
+        g_brdf_ind_out = ind + 5 * k;
+        (void)radiance_nee(s, &c, &lights, &d, xy[2 * k], xy[2 * k + 1], NULL, NULL, NULL);
+        g_brdf_ind_out = NULL;
+    }
+}
+
 void por_brdf_lookup(const double* table, const double* angles4, int n, double* rgb, int* ind) {
     for (int i = 0; i < n; i++) {
         const double* a = angles4 + 4 * i;

@@ -139,6 +139,22 @@ def synthetic_brdf_table(table_id, negative_fraction=0.03):
     return v
 
 
+def smooth_brdf_table(table_id):
+    """Synthetic MERL-format table whose value is a smooth function of the three table angles at the
+    bin centres, pi-periodic in phi_diff like a real isotropic BRDF: neighbouring bins (bins 0 and 179
+    of phi_diff included) hold nearly equal values.  Positive everywhere; channels differ by a factor."""
+    k = np.arange(90, dtype=np.float64) + 0.5
+    theta_half = (k / 90.0) ** 2 * (np.pi / 2.0)
+    theta_diff = k * (np.pi / 180.0)
+    phi_diff = (np.arange(180, dtype=np.float64) + 0.5) * (np.pi / 180.0)
+    lobe = np.cos(theta_half)[:, None, None] ** (4 + 2 * table_id)
+    fres = (1.0 - np.cos(theta_diff)[None, :, None]) ** 3
+    aniso = np.sin(theta_diff)[None, :, None] ** 2 * (1.0 + 0.8 * np.cos(2.0 * phi_diff)[None, None, :])
+    base = 0.15 + 0.45 * lobe + 0.25 * fres + 0.15 * aniso  # (90, 90, 180), in [0.15, 1.3]
+    plane = (1500.0 * base).reshape(-1)
+    return np.concatenate([plane * (0.9 + 0.02 * table_id), plane * 0.8, plane * (0.6 + 0.05 * table_id)])
+
+
 def write_brdf_file(path, table):
     """Write a table in the reference's .binary format (MatusikBRDF.h:90-103)."""
     with open(path, "wb") as f:
@@ -295,6 +311,14 @@ class Renderer:
             )
         )
         return out
+
+    def trace_brdf_indices(self, it_idx, xy):
+        it_idx = np.ascontiguousarray(it_idx, dtype=np.int32)
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        n = it_idx.shape[0]
+        ind = np.zeros((n, 5), dtype=np.int32)
+        _check(lib().pt_trace_brdf_indices(self._h, _p(it_idx), _p(xy), n, _p(ind)))
+        return ind
 
     def frame_layout(self, iteration):
         ys = np.zeros(self.height)

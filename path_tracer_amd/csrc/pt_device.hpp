@@ -973,9 +973,11 @@ PTD_INLINE int brdf_index_of_vectors(const double* __restrict__ bins, V3 vin, V3
 
 // The measured-material term of a lit vertex (the incoming and outgoing directions in the roles
 // vector_to_spherical, raytrace3.cpp:725-728, and lookup_brdf_val, MatusikBRDF.h:50-80, give them).
-PTD_INLINE V3 measured_term(const double* __restrict__ table,
-                                                      const double* __restrict__ bins, V3 bd, V3 nprime) {
-    return brdf_rgb(table, brdf_index_of_vectors(bins, bd, nprime));
+PTD_INLINE V3 measured_term(const double* __restrict__ table, const double* __restrict__ bins, V3 bd, V3 nprime,
+                            int* ind_out = nullptr) {
+    const int ind = brdf_index_of_vectors(bins, bd, nprime);
+    if (ind_out) *ind_out = ind;
+    return brdf_rgb(table, ind);
 }
 
 // One lit vertex of the NEE loop (next_event.cpp:442-463): L = ((L + (Le*Lc)*flux) * c) + e.
@@ -983,7 +985,7 @@ PTD_INLINE V3 measured_term(const double* __restrict__ table,
 // for vertex 0, next_event.cpp:443-447).
 template <bool MEASURED, bool ELIDE>
 PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& dr, int light, V3 P, V3 bd,
-                         V3 next_point, V3 L) {
+                         V3 next_point, V3 L, int* brdf_ind_out = nullptr) {
     V3 scale;
     const V3 lterm = light_term(S, light);
     const bool direct_is_zero = (lterm.x == 0.0) & (lterm.y == 0.0) & (lterm.z == 0.0);
@@ -1003,7 +1005,7 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
     if (MEASURED && m.material == kMeasured) {
         // Defined by this build: the table RGB replaces the scalar flux (the reference's own
         // lookups, raytrace3.cpp:646-676, are never executed).
-        V3 f = measured_term(S.brdf[m.brdf_id], S.brdf_bins, bd, nprime);
+        V3 f = measured_term(S.brdf[m.brdf_id], S.brdf_bins, bd, nprime, brdf_ind_out);
         scale = mul(lterm, f);
     } else {
         V3 light_brdf = bounce(m, dr, bd, nprime);
@@ -1018,7 +1020,8 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
 //       evaluation from the deepest hit outwards.
 //  NEE: pixel body of Renderer::iterate next_event.cpp:384-470 with trace() next_event.cpp:491-530.
 template <int EST, bool MEASURED, bool ELIDE>
-PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y, const Records& rec) {
+PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y, const Records& rec,
+                                 int* brdf_ind = nullptr) {
     const DGeom* __restrict__ geom = S.geom;
     const DMat* __restrict__ mat = S.mat;
     V3 o = ld3(S.cam_o);
@@ -1072,7 +1075,8 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         PT_PROF(kProfNeeVertex);
         V3 next_point = campt;
         if (gi >= 1) next_point = rec.point(gi - 1);
-        L = nee_vertex<MEASURED, ELIDE>(S, geom[hit], mat[hit], dr, light, P, bd, next_point, L);
+        L = nee_vertex<MEASURED, ELIDE>(S, geom[hit], mat[hit], dr, light, P, bd, next_point, L,
+                                        brdf_ind ? brdf_ind + gi : nullptr);
     }
     R.rgb = L;
     return R;

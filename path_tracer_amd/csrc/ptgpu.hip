@@ -307,7 +307,7 @@ template <int EST, bool MEASURED>
 __global__ void __launch_bounds__(kBlock) k_trace_paths(DScene S, const int32_t* __restrict__ it_idx2,
                                                         const double* __restrict__ xy, int n, double* rgb,
                                                         int32_t* nrec, int32_t* bodies, double* points,
-                                                        int32_t* visible, int32_t* used) {
+                                                        int32_t* visible, int32_t* used, int32_t* brdf_ind = nullptr) {
     __shared__ double s_pts[kMaxDepth * 3 * kBlock];
     __shared__ int8_t s_bod[kMaxDepth * kBlock];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,7 +320,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_paths(DScene S, const int32_t*
     rec.bod = s_bod;
     rec.stride = kBlock;
     rec.tid = threadIdx.x;
-    PathResult R = trace_path<EST, MEASURED, false>(S, dr, xy[2 * i], xy[2 * i + 1], rec);
+    int ind5[kMaxDepth] = {-1, -1, -1, -1, -1};
+    PathResult R = trace_path<EST, MEASURED, false>(S, dr, xy[2 * i], xy[2 * i + 1], rec, MEASURED && brdf_ind ? ind5 : nullptr);
+    if (MEASURED && brdf_ind)
+        for (int k = 0; k < kMaxDepth; ++k) brdf_ind[5 * i + k] = ind5[k];
     if (rgb) {
         const V3 c = canonical_nan(R.rgb);
         rgb[3 * i] = c.x;
@@ -1536,6 +1539,29 @@ int pt_trace_paths(pt_scene* s, const int32_t* it_idx2, const double* xy, int n,
     if (points) HIP_TRY(hipMemcpy(points, d_pts, sizeof(double) * 15 * n, hipMemcpyDeviceToHost));
     if (visible) HIP_TRY(hipMemcpy(visible, d_vis, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     if (used) HIP_TRY(hipMemcpy(used, d_used, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_trace_brdf_indices(pt_scene* s, const int32_t* it_idx2, const double* xy, int n, int32_t* ind) {
+    if (!s || !it_idx2 || !xy || !ind || n < 0) return fail(PT_ERR_INVALID, "pt_trace_brdf_indices: bad argument");
+    if (s->estimator != PT_EST_NEE || !s->has_measured)
+        return fail(PT_ERR_INVALID, "pt_trace_brdf_indices: the scene has no measured body under next-event estimation");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = check_measured_tables(s);
+    if (rc) return rc;
+    Tmp<int32_t> d_ii, d_ind;
+    Tmp<double> d_xy;
+    HIP_TRY(d_ii.alloc((size_t)2 * n));
+    HIP_TRY(d_xy.alloc((size_t)2 * n));
+    HIP_TRY(d_ind.alloc((size_t)5 * n));
+    HIP_TRY(hipMemcpy(d_ii, it_idx2, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_xy, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_trace_paths<kEstNEE, true>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, s->ds, d_ii, d_xy, n,
+                       (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)nullptr,
+                       (int32_t*)nullptr, (int32_t*)d_ind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(ind, d_ind, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -215,6 +215,14 @@ class Port:
         self.lib.por_trace_paths(C.byref(s), _p(it_idx), _p(xy), n, _p(rgb), _p(nrec), _p(bodies), _p(points), _p(vis), _p(used))
         return dict(rgb=rgb, nrec=nrec, bodies=bodies, points=points, visible=vis, draws=used)
 
+    def trace_brdf_indices(self, s, it_idx, xy):
+        it_idx = np.ascontiguousarray(it_idx, dtype=np.int32)
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        n = it_idx.shape[0]
+        ind = np.zeros((n, 5), dtype=np.int32)
+        self.lib.por_trace_brdf_indices(C.byref(s), _p(it_idx), _p(xy), n, _p(ind))
+        return ind
+
     def rng_fill(self, seed, it, dom, idx, n):
         k = np.zeros(n, dtype=np.int32)
         u = np.zeros(n)

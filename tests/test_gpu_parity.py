@@ -227,6 +227,44 @@ def test_measured_brdf_lookup_and_render(port):
     r.close()
 
 
+def test_measured_render_within_tolerance_on_smooth_tables(port):
+    """Configuration with measured materials, on tables that vary smoothly with the table angles (as
+    real measured data does): the image must match the oracle within the stated tolerance, per-pixel
+    RMSE <= 1e-3 relative, and every lookup must use the oracle's table bin or — where phi_diff is
+    rounding noise of the sin/cos/atan2 in use — its neighbour on the cyclic phi_diff axis."""
+    W, H, n_it = 64, 48, 8
+    r = pt.Renderer(pt.preset("nee15_measured", W, H, seed=6))
+    tables = [pt.smooth_brdf_table(k) for k in range(4)]
+    for k, t in enumerate(tables):
+        r.brdf_upload(k, t)
+    s = oracle_scene(port, r, W, H, 6, tables=tables)
+    want, _ = port.render(s, MODE_PIXEL, 0, n_it)
+    got = r.render(0, n_it)
+    rmse = np.sqrt(np.mean((got - want) ** 2)) / np.mean(want)
+    assert rmse <= 1e-3, rmse
+    worst = np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3))
+    assert worst <= 2e-2, worst  # no single pixel off by more than a neighbouring bin can explain
+    differs = (got.view(np.uint64) != want.view(np.uint64)).any(axis=2)
+    assert differs.mean() < 0.02
+    # lookup by lookup
+    rng = np.random.default_rng(13)
+    n = 30000
+    it_idx = np.stack([rng.integers(0, 7200, n), rng.integers(0, 1 << 20, n)], axis=1).astype(np.int32)
+    xy = rng.uniform(0, 1, size=(n, 2))
+    gi = r.trace_brdf_indices(it_idx, xy)
+    oi = port.trace_brdf_indices(s, it_idx, xy)
+    assert np.array_equal(gi < 0, oi < 0)  # the same vertices are lit and measured
+    assert (gi >= 0).sum() > n  # the test has lookups to compare
+    bad = np.argwhere(gi != oi)
+    assert len(bad) < 2e-3 * (gi >= 0).sum(), len(bad)
+    for k, j in bad:
+        g, o = int(gi[k, j]), int(oi[k, j])
+        assert g // 180 == o // 180, (k, j, g, o)  # same theta_half and theta_diff bins
+        dphi = abs(g % 180 - o % 180)
+        assert dphi in (1, 179), (k, j, g, o)  # neighbours on the cyclic phi_diff axis
+    r.close()
+
+
 def test_measured_index_from_vectors(port):
     """The estimator's trigonometry-free table index (from the two direction vectors) against the
     reference's chain vector_to_spherical -> lookup_brdf_val evaluated with libm on the host."""
