@@ -892,69 +892,76 @@ PTD_INLINE int bins_passed(const double* __restrict__ T, double v) {
     return pos;
 }
 
+// 1/sqrt(x) and 1/x to within an ulp or two: the hardware estimate (2^-26) and two Newton steps.
+// 0 gives NaN (0 * inf) where the quotient forms would give 0/0 = NaN or x/0 = inf; callers treat
+// those poles separately.
+PTD_INLINE double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double g = x * y, hh = 0.5 * y;
+        const double r = __builtin_fma(-g, hh, 0.5);
+        y = __builtin_fma(y, r, y);
+    }
+    return y;
+}
+PTD_INLINE double rcp_nr(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
+}
+
+// cos / sin of theta = atan(y/x) and of phi = acos(z/len) (vector_to_spherical, raytrace3.cpp:725-728)
 PTD_INLINE void spherical_sincos(V3 v, double& ct, double& st, double& cp, double& sp) {
-    const double h = sqrt(v.x * v.x + v.y * v.y);
-    ct = fabs(v.x) / h;
-    st = __builtin_copysign(1.0, v.x) * v.y / h;
-    double c = v.z / sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    const double h2 = v.x * v.x + v.y * v.y;
+    const double ih = rsqrt_nr(h2), il = rsqrt_nr(h2 + v.z * v.z);
+    ct = fabs(v.x) * ih;
+    st = __builtin_copysign(1.0, v.x) * v.y * ih;
+    double c = v.z * il;
     if (!(fabs(c) <= 1.0)) c = __builtin_nan("");  // acos outside [-1, 1]
     cp = c;
-    sp = sqrt((1.0 - c) * (1.0 + c));
+    sp = (h2 * ih) * il;  // sqrt(x^2 + y^2) / len
 }
 
 PTD_INLINE int brdf_index_of_vectors(const double* __restrict__ bins, V3 vin, V3 vout) {
     double ct_i, st_i, cp_i, sp_i, ct_o, st_o, cp_o, sp_o;
     spherical_sincos(vin, ct_i, st_i, cp_i, sp_i);
     spherical_sincos(vout, ct_o, st_o, cp_o, sp_o);
-    // std_coords_to_half_diff_coords :159-205
-    const double in_vec_z = ct_i, in_vec_x = st_i * cp_i, in_vec_y = st_i * sp_i;
-    double in[3] = {in_vec_x, in_vec_y, in_vec_z};
-    brdf_normalize(in);
-    const double out_vec_z = ct_o, out_vec_x = st_o * cp_o, out_vec_y = st_o * sp_o;
-    double half[3] = {(in_vec_x + out_vec_x) / 2.0, (in_vec_y + out_vec_y) / 2.0, (in_vec_z + out_vec_z) / 2.0};
-    brdf_normalize(half);
-    const double r = sqrt(half[0] * half[0] + half[1] * half[1]);  // sin(theta_half)
+    // std_coords_to_half_diff_coords :159-205.  `in` has unit length up to rounding; the reference's
+    // normalisation of it (:169) changes the last place only and is left out.
+    const double in[3] = {st_i * cp_i, st_i * sp_i, ct_i};
+    const double out_vec_x = st_o * cp_o, out_vec_y = st_o * sp_o, out_vec_z = ct_o;
+    // half = normalize((in + out) / 2): the factor 1/2 cancels
+    double half[3] = {in[0] + out_vec_x, in[1] + out_vec_y, in[2] + out_vec_z};
+    const double ihl = rsqrt_nr(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]);
+    half[0] *= ihl;
+    half[1] *= ihl;
+    half[2] *= ihl;
+    const double r2 = half[0] * half[0] + half[1] * half[1];
+    const double ir = rsqrt_nr(r2);
+    double r = r2 * ir;  // sin(theta_half)
     // rotation by -fi_half about (0,0,1); on the pole (r == 0) atan2 gives 0 or pi
-    double cos1 = half[0] / r, sin1 = -half[1] / r;
-    if (r == 0.0) {
+    double cos1 = half[0] * ir, sin1 = -half[1] * ir;
+    if (r2 == 0.0) {
         cos1 = __builtin_copysign(1.0, half[0]);
         sin1 = 0.0;
+        r = 0.0;
     }
-    const double bi_normal[3] = {0.0, 1.0, 0.0};
-    const double normal[3] = {0.0, 0.0, 1.0};
-    double temp[3], diff[3];
-    {
-        const double* vector = in;
-        const double* axis = normal;
-        temp[0] = vector[0] * cos1;
-        temp[1] = vector[1] * cos1;
-        temp[2] = vector[2] * cos1;
-        double t = axis[0] * vector[0] + axis[1] * vector[1] + axis[2] * vector[2];
-        t = t * (1.0 - cos1);
-        temp[0] += axis[0] * t;
-        temp[1] += axis[1] * t;
-        temp[2] += axis[2] * t;
-        temp[0] += (axis[1] * vector[2] - axis[2] * vector[1]) * sin1;
-        temp[1] += (axis[2] * vector[0] - axis[0] * vector[2]) * sin1;
-        temp[2] += (axis[0] * vector[1] - axis[1] * vector[0]) * sin1;
-    }
-    {
-        // rotation by -theta_half about (0,1,0): cos = half.z, sin = -r
-        const double cos2 = half[2], sin2 = -r;
-        const double* vector = temp;
-        const double* axis = bi_normal;
-        diff[0] = vector[0] * cos2;
-        diff[1] = vector[1] * cos2;
-        diff[2] = vector[2] * cos2;
-        double t = axis[0] * vector[0] + axis[1] * vector[1] + axis[2] * vector[2];
-        t = t * (1.0 - cos2);
-        diff[0] += axis[0] * t;
-        diff[1] += axis[1] * t;
-        diff[2] += axis[2] * t;
-        diff[0] += (axis[1] * vector[2] - axis[2] * vector[1]) * sin2;
-        diff[1] += (axis[2] * vector[0] - axis[0] * vector[2]) * sin2;
-        diff[2] += (axis[0] * vector[1] - axis[1] * vector[0]) * sin2;
-    }
+    // rotate_vector :133-156 about (0,0,1) by (cos1, sin1), then about (0,1,0) by (half.z, -r);
+    // the terms that multiply the zero components of the axes are dropped
+    double temp[3];
+    temp[0] = in[0] * cos1 - in[1] * sin1;
+    temp[1] = in[1] * cos1 + in[0] * sin1;
+    temp[2] = in[2];
+    const double cos2 = half[2], sin2 = -r;
+    double diff[3];
+    diff[0] = temp[0] * cos2 + temp[2] * sin2;
+    diff[1] = temp[1];
+    diff[2] = temp[2] * cos2 - temp[0] * sin2;
     // theta_half_index(acos(half.z)) :211-223
     const int i_half = bins_passed<128>(bins + kBinsHalf, half[2]);
     // theta_diff_index(acos(diff.z)) :228-237; acos is NaN outside [-1, 1] and NaN indexes bin 0
@@ -967,7 +974,7 @@ PTD_INLINE int brdf_index_of_vectors(const double* __restrict__ bins, V3 vin, V3
     if (diff[1] == 0.0)
         i_phi = (!__builtin_signbit(diff[1]) && __builtin_signbit(diff[0]) && !(diff[0] != diff[0])) ? 179 : 0;
     else
-        i_phi = bins_passed<256>(bins + kBinsPhi, diff[0] / diff[1]);
+        i_phi = bins_passed<256>(bins + kBinsPhi, diff[0] * rcp_nr(diff[1]));
     return i_phi + i_diff * 360 / 2 + i_half * 360 / 2 * 90;
 }
 
