@@ -762,17 +762,26 @@ PTD_INLINE void vector_to_spherical(V3 in, double& theta, double& phi) {
     phi = acos(in.z / sqrt(in.x * in.x + in.y * in.y + in.z * in.z));
 }
 
-// Bounding-sphere screen of two groups: a member can only be hit when the ray starts inside the
-// bound (c < 0) or meets it ahead (disc >= 0 and b < 0); evaluated in float with the error bounds
-// of make_rayf (e_disc also bounds the error of c).  R^2 = +inf always passes, -inf never.
+// Bounding-sphere screen of two groups (records hold the centre and, in r2, the RADIUS R, rounded
+// outwards): a member can only be hit when the ray starts inside the bound (c < 0) or meets it ahead
+// (disc >= 0 and b < 0); evaluated in float with the error bounds of make_rayf (e_disc also bounds the
+// error of c and of |D|^2).  R = +inf always passes, -inf never.
+// Distance cut: a sphere inside the bound that the reference's formula hits from outside has
+// t = C / (beta + sqrt(beta^2 - C)) >= C / (2 beta) with C = |D|^2 - r^2 >= delta |D| and
+// beta = -D.d <= |D| |d|, delta = |o - c_B| - R the distance from the origin to the bound: so
+// t >= delta / (2 |d|).  A lane whose nearest hit so far is mint cannot improve on it inside a bound
+// with delta > tau = 2 |d| mint (tau is passed rounded up; +inf disables the cut).
 PTD_INLINE void group_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
-                                      float e_b, const DScreen2& sc, lanemask& m0, lanemask& m1) {
+                                      float e_b, float tau, const DScreen2& sc, lanemask& m0, lanemask& m1) {
     f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
     f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
-    f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
+    f32x2 D2 = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx));
+    f32x2 cf = D2 - sc.r2 * sc.r2;
     f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
-    m0 = PTD_MASK(!(cf.x > e_disc)) | (PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b)));
-    m1 = PTD_MASK(!(cf.y > e_disc)) | (PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b)));
+    f32x2 reach = sc.r2 + tau;
+    f32x2 far2 = reach * reach;
+    m0 = (PTD_MASK(!(cf.x > e_disc)) | (PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b)))) & PTD_MASK(!(D2.x - e_disc > far2.x));
+    m1 = (PTD_MASK(!(cf.y > e_disc)) | (PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b)))) & PTD_MASK(!(D2.y - e_disc > far2.y));
 }
 
 // ---- the estimator ---------------------------------------------------------------------

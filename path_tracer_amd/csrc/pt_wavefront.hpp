@@ -144,7 +144,12 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     const RayF rf = make_rayf(o, d, S.sphere_c1max, S.sphere_r2max);
     const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
     const float e_disc = rf.e_disc, e_b = rf.e_b;
-    const lanemask long_dir = PTD_MASK(!(fdx * fdx + fdy * fdy + fdz * fdz <= 1.000001f));
+    const float dlen2 = fdx * fdx + fdy * fdy + fdz * fdz;
+    const lanemask long_dir = PTD_MASK(!(dlen2 <= 1.000001f));
+    // tau = 2 |d| mint of the distance cut (group_possible2_masks), rounded up; lanes outside the
+    // screen's validity (|d| > 1, NaN) never cut
+    const float two_len = (dlen2 <= 1.000001f) ? 2.0f * __builtin_sqrtf(dlen2) * 1.00001f : INFINITY;
+    auto cut_of = [&](double m) { return two_len * ((float)m * 1.00001f); };
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     if (active) {
@@ -160,6 +165,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     Pending pd;
     pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
     pd.n = 0u;
+    float tau = cut_of(mint);  // DBL_MAX converts to +inf: no cut before the first hit
     const int n_groups = S.n_groups;
     for (int base = 0; base < n_groups; base += kTileGroups) {
         const int cnt = min(kTileGroups, n_groups - base);  // a multiple of 2 kSuperGroups
@@ -179,7 +185,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
         if (active) {
             for (int sp = 0; sp < cnt / kSuperGroups / 2; ++sp) {
                 lanemask reach[2];
-                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tile->supers[sp], reach[0], reach[1]);
+                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->supers[sp], reach[0], reach[1]);
                 if (((reach[0] | reach[1] | long_dir)) == 0) continue;
 #pragma unroll 1
                 for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
@@ -187,7 +193,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
                     if ((reach[sside] | long_dir) == 0) continue;
                     const int gp = sp * kSuperGroups + gq;
                     lanemask enter[2];
-                    group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tile->bounds[gp], enter[0], enter[1]);
+                    group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->bounds[gp], enter[0], enter[1]);
                     if (((enter[0] | enter[1] | long_dir)) == 0) continue;
 #pragma unroll 1
                     for (int side = 0; side < 2; ++side) {
@@ -210,7 +216,10 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
                                 for (uint32_t j = 0; j < 4; ++j)
                                     pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
                                 pd.n += sel32(need[h], 1u, 0u);
-                                if (PTD_MASK(pd.n == 4u) != 0) pending_eval(S, pd, o, d, skip, hit, mint);
+                                if (PTD_MASK(pd.n == 4u) != 0) {
+                                    pending_eval(S, pd, o, d, skip, hit, mint);
+                                    tau = cut_of(mint);
+                                }
                             }
                         }
                     }

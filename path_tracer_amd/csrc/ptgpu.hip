@@ -801,10 +801,10 @@ struct SceneUpload {
                         const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
                         R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
                     }
-                    fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
+                    fr2 = std::nextafter((float)(R * (1.0 + 2e-6)), INFINITY);  // the record keeps R, see group_possible2_masks
                     if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
                     c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
-                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2 * fr2 * 1.00001f);
                 }
                 r.cx[g & 1] = fc[0];
                 r.cy[g & 1] = fc[1];
@@ -836,12 +836,12 @@ struct SceneUpload {
                         const DScreen2& b = bounds[g / 2];
                         if (!(b.r2[g & 1] >= 0.0f)) continue;
                         const double dx = (double)b.cx[g & 1] - fc[0], dy = (double)b.cy[g & 1] - fc[1], dz = (double)b.cz[g & 1] - fc[2];
-                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt((double)b.r2[g & 1]));
+                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)b.r2[g & 1]);  // r2 holds the group's R
                     }
-                    fr2 = std::nextafter((float)(R * R * (1.0 + 1e-6)), INFINITY);
+                    fr2 = std::nextafter((float)(R * (1.0 + 2e-6)), INFINITY);
                     if (!(fr2 >= 0.0f)) fr2 = INFINITY;
                     c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
-                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2);
+                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2 * fr2 * 1.00001f);
                 }
                 DScreen2& r = supers[sg / 2];
                 r.cx[sg & 1] = fc[0];
@@ -849,6 +849,21 @@ struct SceneUpload {
                 r.cz[sg & 1] = fc[2];
                 r.r2[sg & 1] = fr2;
             }
+            // An empty group or super-group (radius -inf above) must never be entered.  With the record
+            // holding R, not R^2, that is said by a centre far outside any scene and R = 0: for
+            // |d| <= 1 the discriminant is about -|D|^2 (1 - cos^2) - ... <= -2e36, far below every error
+            // bound.  (Rays with a longer direction examine every group anyway; the member slots of an
+            // empty group can never pass.)
+            auto park_empty = [](std::vector<DScreen2>& recs) {
+                for (DScreen2& r : recs)
+                    for (int h = 0; h < 2; ++h)
+                        if (!(r.r2[h] >= 0.0f)) {
+                            r.cx[h] = r.cy[h] = r.cz[h] = 1e18f;
+                            r.r2[h] = 0.0f;
+                        }
+            };
+            park_empty(bounds);
+            park_empty(supers);
             int rcg;
             if ((rcg = s->d_grp_supers.ensure(sizeof(DScreen2) * supers.size()))) return rcg;
             HIP_TRY(hipMemcpy(s->d_grp_supers.p, supers.data(), sizeof(DScreen2) * supers.size(), hipMemcpyHostToDevice));

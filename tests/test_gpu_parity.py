@@ -372,6 +372,20 @@ def test_large_scene_uses_lds_tiled_scan(port):
         r.close()
 
 
+def test_ten_thousand_bodies_across_many_blocks(port):
+    """The 10 000-body scene at a size where every stage of the wavefront pipeline spans many blocks
+    (64x48x2 = 6144 paths, 24 blocks of 256): ray sorting, queue compaction and the tiled scan
+    against the oracle, bit for bit (about ten seconds of CPU)."""
+    W, H, n_it = 64, 48, 2
+    r = pt.Renderer(pt.preset("synthetic10k", W, H, seed=4))
+    s = oracle_scene(port, r, W, H, 4)
+    want, _ = port.render(s, MODE_PIXEL, 0, n_it)
+    got = r.render(0, n_it)
+    assert same_bits(got, want)
+    assert np.count_nonzero(got) > 0.3 * got.size
+    r.close()
+
+
 def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
     """`next_event W H iters threads` and `main ...`: PPM bytes equal save() of the oracle's buffer, with
     the reference's worker arithmetic (iters/threads frames per worker, divide by the requested total)."""
