@@ -31,8 +31,10 @@ typedef enum pt_status {
     PT_ERR_UNSUPPORTED = -5
 } pt_status;
 
-enum { PT_SPHERE = 0, PT_PLANE = 1, PT_RECTANGLE = 2 };           /* Sphere main.cpp:198, Plane main.cpp:171,
+enum { PT_SPHERE = 0, PT_PLANE = 1, PT_RECTANGLE = 2,             /* Sphere main.cpp:198, Plane main.cpp:171,
                                                                       Rectangle raytrace3.cpp:244 (PT_EST_PT only) */
+       PT_RECTANGLE_MT = 3 };                                      /* Rectangle light_tracing.cpp:477-575: two
+                                                                      Moller-Trumbore triangle tests (PT_EST_PT only) */
 enum { PT_DIFFUSE = 0, PT_CHROME = 1, PT_GLASS = 2, PT_MEASURED = 3 }; /* Material :230, Chrome :257, Glass :269,
                                                                       MatusikBRDF.h:37 */
 enum { PT_EST_PT = 0, PT_EST_NEE = 1 };                            /* main.cpp trace() / next_event.cpp iterate() */
@@ -45,6 +47,12 @@ enum { PT_EST_PT = 0, PT_EST_NEE = 1 };                            /* main.cpp t
 #define PT_F_RAYTRACE3 2u /* PT_EST_PT as raytrace3.cpp runs it (shoot_trace = false, raytrace3.cpp:555): a hit
                              needs t > 0.0000001L (:776) instead of t > 0, and a level returns
                              color * (trace(next) + V3()) + emission (:805,840). */
+
+#define PT_F_PIXEL_GRID 4u /* Samples sit on the pixel grid, as Renderer::ray_iterate takes them
+                              (light_tracing.cpp:774-790): pixel (col, row) looks through
+                              getRay((double)col / (double)width, (double)row / (double)height), every row is
+                              full and no jitter is drawn.  Default (flag clear): the jittered running sums of
+                              Renderer::iterate (main.cpp:352-357). */
 
 /* One Body (main.cpp:309-318): a Shape plus a Material, by value.
  * `normal` is the Plane constructor ARGUMENT (main.cpp:176-179); the library normalises it the way
@@ -61,8 +69,9 @@ typedef struct pt_body {
     double reflection; /* Glass only */
     int32_t brdf_id;   /* PT_MEASURED only: table slot 0..PT_MAX_BRDF-1, else -1 */
     int32_t reserved;
-    double corners[12]; /* PT_RECTANGLE only: the constructor arguments p1, p2, p3, p4 (raytrace3.cpp:254);
-                           `normal` is then an output of pt_body_construct, center and radius are unused */
+    double corners[12]; /* PT_RECTANGLE, PT_RECTANGLE_MT: the constructor arguments p1, p2, p3, p4
+                           (raytrace3.cpp:254, light_tracing.cpp:484); `normal` is then an output of
+                           pt_body_construct, center and radius are unused */
 } pt_body;
 
 /* Camera(origin, topleft, topright, bottomleft): main.cpp:144-152. */
@@ -100,8 +109,9 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out);
 int pt_scene_destroy(pt_scene* scene);
 
 /* Apply the Shape constructors to one body in place: a Plane stores normalize(normal)
- * (main.cpp:176-179); a Sphere is unchanged; a Rectangle stores normalize((p3-p1) x (p2-p1)) in
- * `normal` (raytrace3.cpp:260).  pt_scene_create does this to its own copy. Host only. */
+ * (main.cpp:176-179); a Sphere is unchanged; a Rectangle of either kind stores
+ * normalize((p3-p1) x (p2-p1)) in `normal` (raytrace3.cpp:260, light_tracing.cpp:494).
+ * pt_scene_create does this to its own copy. Host only. */
 int pt_body_construct(pt_body* body);
 
 /* The bodies as stored after construction (plane normals normalised). Returns the count. */
@@ -117,6 +127,15 @@ int pt_brdf_load_file(pt_scene* scene, int brdf_id, const char* path);
  * Default: rank 0 of 1.  The reference's counterpart is worker()'s per-thread split
  * (main.cpp:436-458, 642-645). */
 int pt_set_partition(pt_scene* scene, int rank, int world, int tile_w, int tile_h);
+
+/* Row-range sharding, the work split of the light-tracing family: Renderer::ray_iterate(start_row,
+ * row_count) fills buffer[start_row * width ...] row by row (light_tracing.cpp:774-790).  After
+ * pt_set_rows the handle renders only destination pixels of rows [start_row, start_row + row_count);
+ * it combines with pt_set_partition (a pixel must satisfy both).  Default: every row.
+ *   pt_row_split: the rows main() hands worker `worker` of `workers` (light_tracing.cpp:1441-1451):
+ *   height / workers rows each, the last worker also takes the remainder. */
+int pt_set_rows(pt_scene* scene, int start_row, int row_count);
+int pt_row_split(int height, int workers, int worker, int* start_row, int* row_count);
 
 /* The exchange step of a multi-GPU render, in place of the mutex-guarded sum of worker()
  * (main.cpp:444-457): destination tiles are disjoint, so the ranks gather each other's owned tiles
@@ -221,7 +240,9 @@ int pt_save_ppm(const double* buffer, int samples, int width, int height, const 
  * (main.cpp:473-607), "pt15" (main.cpp's estimator on the 15-body scene), "nee15_lit" (nee15 with light
  * colour 1 so the direct term is non-zero), "nee15_measured" (nee15_lit with bodies 0,1,6,7 measured),
  * "nee32" (next_event's estimator on the 32-body scene), "bipath23" (next_event's estimator on the 23-body, 10-light scene of bipath2.cpp:605-725) and
- * "synthetic10k" / "synthetic1k" (nee15 room + 9985 / 985 extra spheres).  Fills desc (desc->bodies = bodies). */
+ * "synthetic10k" / "synthetic1k" (nee15 room + 9985 / 985 extra spheres), and "light_room32" (main.cpp's estimator
+ * on the 32-body scene of light_tracing.cpp:1237-1415: six balls, eight Moller-Trumbore rectangles, 18 ball
+ * lights; its camera; PT_F_PIXEL_GRID).  Fills desc (desc->bodies = bodies). */
 int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc, pt_body* bodies, int cap);
 
 /* Statistics of the last pt_render* call on this handle. */

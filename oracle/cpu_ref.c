@@ -36,6 +36,9 @@
                               t > 0.0000001L (raytrace3.cpp:776) and the radiance is
                               color*(trace(next) + V3()) + emission (raytrace3.cpp:805,840) */
 
+#define POR_F_PIXEL_GRID 4u /* samples on the pixel grid, as Renderer::ray_iterate takes them
+                               (light_tracing.cpp:785-790): no jitter draws, every row full */
+
 typedef struct por_scene {
     int32_t width, height;
     ptor_camera camera;
@@ -168,9 +171,38 @@ static double intersect_rectangle(const ptor_body* b, v3 o, v3 dir) {
     return (double)-1.0L;
 }
 
+/* Rectangle::tri_intersect2 light_tracing.cpp:537-563 (Moller-Trumbore), EPSILON = 0.000001L (:20).
+ * PARITY UNPINNED: every program that holds this class needs kdtree.h, which is absent, so no build
+ * of the reference can be run against this restatement; it follows the cited lines one for one. */
+static double tri_intersect2(v3 o, v3 dir, v3 p0, v3 edge1, v3 edge2) {
+    v3 pvec = cross(dir, edge2);
+    double det = dot(edge1, pvec);
+    if (det > -0.000001L && det < 0.000001L) return (double)-1.0L;
+    double inv_det = (double)(1.0L / det);
+    v3 tvec = sub(o, p0);
+    double u = dot(tvec, pvec) * inv_det;
+    if ((u < 0.0L) || (u > 1.0L)) return (double)-1.0L;
+    v3 qvec = cross(tvec, edge1);
+    double v = dot(dir, qvec) * inv_det;
+    if ((v < 0.0L) || ((u + v) > 1.0L)) return (double)-1.0L;
+    return dot(edge2, qvec) * inv_det;
+}
+
+/* Rectangle::intersect light_tracing.cpp:501-535 with the edges of the ctor (:490-492). */
+static double intersect_rectangle_mt(const ptor_body* b, v3 o, v3 dir) {
+    v3 p1 = ld3(b->corners), p2 = ld3(b->corners + 3), p3 = ld3(b->corners + 6), p4 = ld3(b->corners + 9);
+    v3 e1 = sub(p2, p1), e2 = sub(p3, p1), e3 = sub(p4, p1);
+    double first_t = tri_intersect2(o, dir, p1, e1, e2);
+    if (first_t != -1.0L) return first_t;
+    first_t = tri_intersect2(o, dir, p1, e2, e3);
+    if (first_t != -1.0L) return first_t;
+    return (double)-1.0L;
+}
+
 /* Plane::intersect main.cpp:181-191; Sphere::intersect main.cpp:210-222. */
 static double intersect(const ptor_body* b, v3 o, v3 dir) {
     if (b->shape == PTOR_RECTANGLE) return intersect_rectangle(b, o, dir);
+    if (b->shape == PTOR_RECTANGLE_MT) return intersect_rectangle_mt(b, o, dir);
     if (b->shape == PTOR_PLANE) {
         v3 n = ld3(b->normal);
         double n_dot_u = dot(n, dir);
@@ -190,7 +222,8 @@ static double intersect(const ptor_body* b, v3 o, v3 dir) {
 
 /* getNormal: Plane main.cpp:192-194, Sphere main.cpp:224-226. */
 static v3 shape_normal(const ptor_body* b, v3 point) {
-    if (b->shape == PTOR_PLANE || b->shape == PTOR_RECTANGLE) return ld3(b->normal); /* raytrace3.cpp:278-281 */
+    if (b->shape == PTOR_PLANE || b->shape == PTOR_RECTANGLE || b->shape == PTOR_RECTANGLE_MT)
+        return ld3(b->normal); /* raytrace3.cpp:278-281, light_tracing.cpp:497-499 */
     return normalize(sub(point, ld3(b->center)));
 }
 
@@ -527,7 +560,51 @@ static void iterate(const por_scene* s, const cam* c, const lightlist* lights, d
     if (d->mode == PTOR_MODE_PIXEL) d->count += dj.count; /* informational only */
 }
 
+/* Renderer::ray_iterate(start_row, row_count) light_tracing.cpp:774-790: the rows' pixels on the
+ * grid, i = start_row * width onwards; the radiance comes from this scene's estimator (the
+ * reference's ray_trace gathers a photon map, which is outside this restatement).  PIXEL mode only:
+ * every pixel has its own stream. */
+static void ray_iterate(const por_scene* s, const cam* c, const lightlist* lights, draws* d, uint32_t it, int start_row,
+                        int row_count, double* buffer) {
+    int i = start_row * s->width;
+    for (int y = start_row; y < (start_row + row_count); y++) {
+        for (int x = 0; x < s->width; x++) {
+            double fx = (double)x / (double)s->width, fy = (double)y / (double)s->height;
+            stream(d, s, it, PTOR_DOM_PIXEL, (uint32_t)i);
+            v3 col;
+            if (s->estimator == PTOR_EST_NEE)
+                col = radiance_nee(s, c, lights, d, fx, fy, NULL, NULL, NULL);
+            else
+                col = radiance_pt(s, d, c->origin, cam_ray_dir(c, fx, fy));
+            buffer[3 * i + 0] += col.x;
+            buffer[3 * i + 1] += col.y;
+            buffer[3 * i + 2] += col.z;
+            i++;
+        }
+    }
+}
+
 /* ======================= exported test API ============================================ */
+
+/* accum[W*H*3] += n_it passes of ray_iterate over rows [start_row, start_row + row_count). */
+void por_render_rows(const por_scene* s, int start_row, int row_count, int first_it, int n_it, double* accum) {
+    cam c = make_cam(&s->camera);
+    lightlist lights = find_lights(s);
+    draws d;
+    memset(&d, 0, sizeof d);
+    d.mode = PTOR_MODE_PIXEL;
+    for (int it = first_it; it < first_it + n_it; it++) ray_iterate(s, &c, &lights, &d, (uint32_t)it, start_row, row_count, accum);
+}
+
+/* The rows of worker i of thread_count: light_tracing.cpp:1441-1451. */
+void por_row_split(int height, int thread_count, int i, int* worker_start_row, int* worker_rows_out) {
+    int row_group_size = height / thread_count;
+    int worker_rows = row_group_size;
+    int worker_start = i * row_group_size;
+    if (i == thread_count - 1) worker_rows = height - (i * row_group_size);
+    *worker_start_row = worker_start;
+    *worker_rows_out = worker_rows;
+}
 
 /* accum[W*H*3] += n_it iterations [first_it, first_it+n_it).  Returns the number of draws. */
 long long por_render(const por_scene* s, int mode, int first_it, int n_it, const int* script, int script_len,

@@ -15,11 +15,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PTGPU_LIB selects another build of the same ABI (development builds with counters)
 LIB_PATH = os.environ.get("PTGPU_LIB") or os.path.join(_HERE, "libptgpu.so")
 
-SPHERE, PLANE, RECTANGLE = 0, 1, 2
+SPHERE, PLANE, RECTANGLE, RECTANGLE_MT = 0, 1, 2, 3  # RECTANGLE_MT: light_tracing.cpp:477-575
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3
 EST_PT, EST_NEE = 0, 1
 F_LIGHT_TRUE_CENTER = 1
 F_RAYTRACE3 = 2  # raytrace3.cpp's path tracer: hit threshold 1e-7, see include/ptgpu.h
+F_PIXEL_GRID = 4  # samples on the pixel grid as Renderer::ray_iterate takes them, light_tracing.cpp:785-790
 BRDF_TABLE_DOUBLES = 3 * 90 * 90 * 180
 DOM_PIXEL, DOM_ROW, DOM_FRAME, DOM_SEQ = 0, 1, 2, 3
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
@@ -229,6 +230,20 @@ class Renderer:
     def set_partition(self, rank, world, tile_w=32, tile_h=8):
         _check(lib().pt_set_partition(self._h, rank, world, tile_w, tile_h))
 
+    def set_rows(self, start_row, row_count):
+        """Render only destination rows [start_row, start_row + row_count) (pt_set_rows)."""
+        _check(lib().pt_set_rows(self._h, int(start_row), int(row_count)))
+
+    def ray_iterate(self, start_row, row_count, n=1):
+        """Renderer::ray_iterate(start_row, row_count) (light_tracing.cpp:774-790): the rows' pixels get
+        n more samples in self.buffer; the other rows are left alone.  The scene decides how a pixel is
+        sampled (F_PIXEL_GRID: on the grid, like the reference's loop)."""
+        self.set_rows(start_row, row_count)
+        try:
+            self.render(self.iterations_done, n, self.buffer)
+        finally:
+            self.set_rows(0, self.height)
+
     def tiles_per_rank(self, world):
         return _check(lib().pt_tiles_per_rank(self._h, int(world)))
 
@@ -327,6 +342,19 @@ class Renderer:
         nrows = C.c_int32()
         _check(lib().pt_frame_layout(self._h, int(iteration), _p(ys), _p(xs), _p(rl), C.byref(nrows)))
         return nrows.value, ys, xs, rl
+
+
+def row_split(height, workers):
+    """[(start_row, row_count)] per worker thread, as main() of the light-tracing programs splits the
+    frame (light_tracing.cpp:1441-1451)."""
+    out = []
+    for i in range(workers):
+        a, b = C.c_int(), C.c_int()
+        rc = lib().pt_row_split(int(height), int(workers), i, C.byref(a), C.byref(b))
+        if rc != 0:
+            raise PtError(f"pt_row_split failed ({rc})")
+        out.append((a.value, b.value))
+    return out
 
 
 def rng_fill(seed, iteration, domain, index, n):

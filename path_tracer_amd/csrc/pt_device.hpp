@@ -51,7 +51,7 @@ constexpr int kGroupBodies = 8;  // member slots per group of the grouped scan
 constexpr int kSuperGroups = 8;  // groups per super-group
 constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
-enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4, kRect = 5 };  // 2..4: device-only, normal = +-e_k; 5: Rectangle
+enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4, kRect = 5, kRectMT = 6 };  // 2..4: device-only, normal = +-e_k; 5: raytrace3's Rectangle; 6: light_tracing's
 enum { kDiffuse = 0, kChrome = 1, kGlass = 2, kMeasured = 3 };
 enum { kEstPT = 0, kEstNEE = 1 };
 enum { kDomPixel = 0, kDomRow = 1, kDomFrame = 2, kDomSeq = 3 };
@@ -185,6 +185,15 @@ struct DRect {  // 128 bytes
     int32_t pad;
 };
 
+// Rectangle of the light-tracing programs (light_tracing.cpp:477-495) as its constructor stores it:
+// p1 and the edges e1 = p2 - p1, e2 = p3 - p1, e3 = p4 - p1.  The body's DGeom carries the normal
+// (shape kRectMT) and, in pad[0], the index of its DRectMT.
+struct DRectMT {  // 128 bytes
+    double p1[3], e1[3], e2[3], e3[3];
+    int32_t body;
+    int32_t pad[7];
+};
+
 // Per-ray data of the single-precision sphere screen (see make_rayf).
 struct RayF {
     float ox, oy, oz, dx, dy, dz;
@@ -230,7 +239,11 @@ struct DScene {
     const DScreen2* scan_screen;
     const DScreen2* scan_screen0;  // the same pairs with |c|^2 - r^2 in place of r^2: the screen from the origin (0,0,0)
     const DRect* scan_rects;       // rectangles in ascending body order
-    int32_t n_planes, n_spheres, n_rects;
+    const DRectMT* scan_rects_mt;  // Moller-Trumbore rectangles in ascending body order
+    // |det| below this counts as parallel: det > -EPSILON && det < EPSILON with the long double literal
+    // 0.000001L (light_tracing.cpp:20,542) is, for a double det, |det| < the smallest double not below it
+    double mt_eps;
+    int32_t n_planes, n_spheres, n_rects, n_rects_mt;
     // A hit needs t > hit_eps: 0 (main.cpp:378, next_event.cpp:502) or, for raytrace3.cpp:776, the
     // largest double below 0.0000001L (t > 0.0000001L for a double t is t > that double).
     double hit_eps;
@@ -331,8 +344,48 @@ PTD_INLINE bool scan_rect(const DRect& r, V3 o, V3 d, double& t) {
     return ok;
 }
 
+// V3::cross light_tracing.cpp:146-151
+PTD_INLINE V3 cross(V3 a, V3 b) { return mk((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)); }
+
+// Rectangle::tri_intersect2 light_tracing.cpp:537-563 (Moller-Trumbore): false where the reference
+// returns -1 from one of its tests.  inv_det = 1.0L / det is the x87 quotient narrowed to double.
+// NaN operands fail none of the reference's comparisons and fall through to the value, as here.
+PTD_INLINE bool tri_mt(V3 o, V3 d, V3 p0, V3 edge1, V3 edge2, double eps, double& t) {
+    const V3 pvec = cross(d, edge2);
+    const double det = dot(edge1, pvec);
+    const double inv_det = ptx::x87_recip(det);
+    const V3 tvec = sub(o, p0);
+    const double u = dot(tvec, pvec) * inv_det;
+    const V3 qvec = cross(tvec, edge1);
+    const double v = dot(d, qvec) * inv_det;
+    t = dot(edge2, qvec) * inv_det;
+    return !((det > -eps) & (det < eps)) & !((u < 0.0) | (u > 1.0)) & !((v < 0.0) | ((u + v) > 1.0));
+}
+// Rectangle::intersect light_tracing.cpp:501-535: the triangle (p1, e1, e2), and only when that
+// returns exactly -1.0 (a miss, or a genuine t of -1) the triangle (p1, e2, e3).  Returns false where
+// the reference returns -1 from both.
+PTD_INLINE bool scan_rect_mt(const DRectMT& r, V3 o, V3 d, double eps, double& t) {
+    const V3 p1 = ld3(r.p1), e2 = ld3(r.e2);
+    double t1;
+    const bool ok1 = tri_mt(o, d, p1, ld3(r.e1), e2, eps, t1);
+    const bool first = ok1 & (t1 != -1.0);
+    t = t1;
+    bool ok = first;
+    if (__builtin_amdgcn_ballot_w64(!first) != 0) {
+        double t2;
+        const bool ok2 = tri_mt(o, d, p1, e2, ld3(r.e3), eps, t2);
+        t = first ? t1 : t2;
+        ok = first | ok2;
+    }
+    return ok;
+}
+
 // Exact Shape::intersect value, signed zeros included (diagnostics).
 PTD_INLINE double intersect_body(const DScene& S, const DGeom& g, V3 o, V3 d) {
+    if (g.shape == kRectMT) {
+        double t;
+        return scan_rect_mt(S.scan_rects_mt[g.pad[0]], o, d, S.mt_eps, t) ? t : -1.0;
+    }
     if (g.shape == kRect) {
         double t;
         return scan_rect(S.scan_rects[g.pad[0]], o, d, t) ? t : -1.0;
@@ -543,6 +596,13 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
             double t;
             const bool ok = scan_rect(rects[k], o, d, t);
             merge_hit(ok, t, rects[k].body, skip, S.hit_eps, hit, mint);
+        }
+        const DRectMT* __restrict__ rects_mt = S.scan_rects_mt;
+        const int n_rects_mt = S.n_rects_mt;
+        for (int k = 0; k < n_rects_mt; ++k) {
+            double t;
+            const bool ok = scan_rect_mt(rects_mt[k], o, d, S.mt_eps, t);
+            merge_hit(ok, t, rects_mt[k].body, skip, S.hit_eps, hit, mint);
         }
     }
     const int n_spheres = S.n_spheres;

@@ -46,6 +46,12 @@ struct Builder {
         memcpy(b->corners, c, sizeof c);
         return b;
     }
+    // Rectangle(p1, p2, p3, p4) light_tracing.cpp:484
+    pt_body* rectangle_mt(const double (&c)[12]) {
+        pt_body* b = rectangle(c);
+        if (b) b->shape = PT_RECTANGLE_MT;
+        return b;
+    }
     pt_body* plane(double cx, double cy, double cz, double nx, double ny, double nz) {
         pt_body* b = next();
         if (!b) return nullptr;
@@ -154,6 +160,44 @@ void scene_raytrace3(Builder& B) {
     light(B.rectangle({1.4, 3.5, 2.5, -1.4, 3.5, 2.5, -1.4, -2.5, 2.5, 1.4, -2.5, 2.5}));  // top light :976-979
 }
 
+// light_tracing.cpp:1237-1415, array order :1408-1413: six balls, the room as six Moller-Trumbore
+// rectangles, a rectangular ceiling light, 18 ball lights sharing one material (colour = emission,
+// :1337) and the "screen" rectangle in front of the camera.
+void scene_light_room32(Builder& B) {
+    auto mat3 = [](pt_body* b, double cr, double cg, double cb, double er, double eg, double eb) {  // Material(color, emission, power)
+        if (!b) return;
+        b->material = PT_DIFFUSE;
+        Builder::set3(b->color, cr, cg, cb);
+        Builder::set3(b->emission, er, eg, eb);
+    };
+    glass(B.sphere(1.0, 2.0, 0.0, 0.5), 1.0, 1.0, 1.0, 1.5, 0.1);       // glass   :1251-1253
+    chrome(B.sphere(-1.1, 2.8, 0.0, 0.5), 0.8, 0.8, 0.8);               // chrome  :1254-1256
+    glass(B.sphere(-0.15, 1.55, -0.4, 0.1), 0.0, 0.8, 0.0, 1.0, 0.2);   // green   :1258-1260
+    glass(B.sphere(0.0, 1.187867, -0.4, 0.1), 0.8, 0.0, 0.0, 1.0, 0.2); // red     :1262-1264
+    glass(B.sphere(0.15, 1.55, -0.4, 0.1), 0.0, 0.0, 0.8, 1.0, 0.2);    // blue    :1266-1268
+    glass(B.sphere(0.0, 1.4, -0.28, 0.1), 1.0, 1.0, 1.0, 1.5, 0.1);     // pyramid :1270-1272
+    diffuse(B.rectangle_mt({-1.9, 4.5, -0.5, 1.9, 4.5, -0.5, 1.9, -2.5, -0.5, -1.9, -2.5, -0.5}), 0.9, 0.9, 0.9);  // floor :1274-1276
+    diffuse(B.rectangle_mt({-1.9, 4.5, 2.5, 1.9, 4.5, 2.5, 1.9, 4.5, -0.5, -1.9, 4.5, -0.5}), 0.9, 0.9, 0.9);      // back  :1277-1279
+    diffuse(B.rectangle_mt({-1.9, -2.5, 2.5, -1.9, 4.5, 2.5, -1.9, 4.5, -0.5, -1.9, -2.5, -0.5}), 0.9, 0.5, 0.5);  // left  :1280-1282
+    diffuse(B.rectangle_mt({1.9, 4.5, 2.5, 1.9, -2.5, 2.5, 1.9, -2.5, -0.5, 1.9, 4.5, -0.5}), 0.5, 0.5, 0.9);      // right :1283-1285
+    diffuse(B.rectangle_mt({1.9, 4.5, 2.5, -1.9, 4.5, 2.5, -1.9, -2.5, 2.5, 1.9, -2.5, 2.5}), 0.9, 0.9, 0.9);      // top   :1286-1288
+    mat3(B.rectangle_mt({1.4, 3.5, 2.4, -1.4, 3.5, 2.4, -1.4, -2.5, 2.4, 1.4, -2.5, 2.4}), 0.0, 0.0, 0.0, 0.3, 0.335, 0.245);  // top light :1309-1312
+    diffuse(B.rectangle_mt({1.9, -2.5, 2.5, -1.9, -2.5, 2.5, -1.9, -2.5, -0.5, 1.9, -2.5, -0.5}), 0.9, 0.9, 0.9);  // front :1290-1292
+    auto ball = [&](double x, double y) { mat3(B.sphere(x, y, 2.1, 0.1), 0.3, 0.47, 0.39, 0.3, 0.47, 0.39); };  // :1337
+    ball(1.9, 3.625);    // right  :1348
+    ball(-1.9, 3.625);   // left   :1352
+    ball(-0.63333, 4.5); // back   :1381
+    ball(0.63333, 4.5);  // back2  :1385
+    const double ys[6] = {2.75, 1.875, 1.0, 0.125, -0.75, -1.625};  // right2..7 / left2..7 :1356-1379
+    for (double y : ys) {
+        ball(1.9, y);
+        ball(-1.9, y);
+    }
+    ball(-0.63333, -2.5);  // front  :1388
+    ball(0.63333, -2.5);   // front2 :1391
+    mat3(B.rectangle_mt({-0.4, 0.1, 0.4, 0.4, 0.1, 0.4, 0.4, 0.1, -0.4, -0.4, 0.1, -0.4}), 0.0, 0.0, 0.0, 0.1, 0.1, 0.1);  // screen :1403-1405
+}
+
 // next_event.cpp:605-689, array order :687
 void scene_nee15(Builder& B) {
     common_bodies(B, true);
@@ -241,8 +285,9 @@ int pt_body_construct(pt_body* b) {
         ref_normalize(b->normal[0], b->normal[1], b->normal[2], n);
         memcpy(b->normal, n, sizeof n);
     }
-    if (b->shape == PT_RECTANGLE) {
-        // this->normal = p3.sub(p1).cross(p2.sub(p1)).normalize()  raytrace3.cpp:260, cross :128-133
+    if (b->shape == PT_RECTANGLE || b->shape == PT_RECTANGLE_MT) {
+        // this->normal = p3.sub(p1).cross(p2.sub(p1)).normalize()  raytrace3.cpp:260, cross :128-133;
+        // light_tracing.cpp:494, cross :146-151
         const double* c = b->corners;
         const double ax = c[6] - c[0], ay = c[7] - c[1], az = c[8] - c[2];
         const double bx = c[3] - c[0], by = c[4] - c[1], bz = c[5] - c[2];
@@ -272,6 +317,10 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
         desc->estimator = PT_EST_PT;
         desc->flags = PT_F_RAYTRACE3;
         scene_raytrace3(B);
+    } else if (s == "light_room32") {  // main.cpp's estimator on light_tracing.cpp's scene, sampled as ray_iterate does
+        desc->estimator = PT_EST_PT;
+        desc->flags = PT_F_PIXEL_GRID;
+        scene_light_room32(B);
     } else if (s == "pt15") {  // main.cpp's estimator on the 15-body / 2-light scene (bipath.cpp:556-558)
         desc->estimator = PT_EST_PT;
         scene_nee15(B);
@@ -318,6 +367,15 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
     if (B.overflow) return PT_ERR_NOMEM;
     desc->bodies = bodies;
     desc->body_count = B.n;
+    return PT_OK;
+}
+
+// The rows main() gives each worker thread: light_tracing.cpp:1441-1451.
+int pt_row_split(int height, int workers, int worker, int* start_row, int* row_count) {
+    if (height < 0 || workers < 1 || worker < 0 || worker >= workers || !start_row || !row_count) return PT_ERR_INVALID;
+    const int row_group_size = height / workers;
+    *start_row = worker * row_group_size;
+    *row_count = worker == workers - 1 ? height - worker * row_group_size : row_group_size;
     return PT_OK;
 }
 

@@ -161,6 +161,13 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
             const bool ok = scan_rect(rects[k], o, d, t);
             merge_hit(ok, t, rects[k].body, skip, S.hit_eps, hit, mint);
         }
+        const DRectMT* __restrict__ rects_mt = S.scan_rects_mt;  // light_tracing.cpp's rectangle, likewise
+        const int n_rects_mt = S.n_rects_mt;
+        for (int k = 0; k < n_rects_mt; ++k) {
+            double t;
+            const bool ok = scan_rect_mt(rects_mt[k], o, d, S.mt_eps, t);
+            merge_hit(ok, t, rects_mt[k].body, skip, S.hit_eps, hit, mint);
+        }
     }
     Pending pd;
     pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
@@ -252,8 +259,13 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         while (slot >= rs[r + 1]) r++;
         int c = slot - rs[r];
         const int CK = (Wd + xstride - 1) / xstride;
-        double x = xs[((size_t)b * H + r) * CK + c / xstride];
-        for (int i = c % xstride; i > 0; --i) x += xstep;
+        double x;
+        if (S.flags & 4u) {
+            x = (double)c / (double)Wd;  // light_tracing.cpp:787
+        } else {
+            x = xs[((size_t)b * H + r) * CK + c / xstride];
+            for (int i = c % xstride; i > 0; --i) x += xstep;
+        }
         double y = ys[(size_t)b * H + r];
         V3 o = ld3(S.cam_o);
         V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157

@@ -62,15 +62,16 @@ struct Partition {
     int tile_w, tile_h;
     int tiles_x, tiles_y;
     int owned_tiles;
+    int row_lo, row_hi;  // destination rows [row_lo, row_hi) of pt_set_rows (0, height by default)
 };
 
-// Destination slot of thread `tid` in owned tile `q`, or -1 outside the image.
+// Destination slot of thread `tid` in owned tile `q`, or -1 outside the image or the row range.
 PTD_INLINE int slot_of(const Partition& P, int q, int tid, int W, int H) {
     int tile = q * P.world + P.rank;
     int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     int px = tx * P.tile_w + tid % P.tile_w;
     int py = ty * P.tile_h + tid / P.tile_w;
-    if (px >= W || py >= H) return -1;
+    if (px >= W || py >= H || py < P.row_lo || py >= P.row_hi) return -1;
     return py * W + px;
 }
 
@@ -79,12 +80,22 @@ PTD_INLINE int slot_of(const Partition& P, int q, int tid, int W, int H) {
 // (x0 = u/W, then x += xstep while x < 0.99999L, main.cpp:355-357), thread 0 also runs the y
 // chain (main.cpp:352-354); a block scan turns row lengths into running-index row starts.
 // xstep/ystep are the doubles the reference initialises from 1.0L/(double)W and 1.0L/(double)H.
+// GRID (PT_F_PIXEL_GRID, Renderer::ray_iterate light_tracing.cpp:785-790): no jitter, every row full,
+// y of row r = (double)r / (double)H; k_trace forms x = (double)c / (double)W itself.
 __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int H, int first_it, double xstep,
                                                        double ystep, double* __restrict__ xs, double* __restrict__ ys,
-                                                       int32_t* __restrict__ row_start, int32_t* __restrict__ npix) {
+                                                       int32_t* __restrict__ row_start, int32_t* __restrict__ npix, int grid) {
     __shared__ int s_part[1024];
     __shared__ int s_nrows;
     const int b = blockIdx.x;
+    if (grid) {
+        for (int r = threadIdx.x; r <= H; r += blockDim.x) {
+            if (r < H) ys[(size_t)b * H + r] = (double)r / (double)H;
+            row_start[(size_t)b * (H + 1) + r] = r * W;
+        }
+        if (threadIdx.x == 0) npix[b] = W * H;
+        return;
+    }
     const uint32_t it = (uint32_t)(first_it + b);
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -187,8 +198,12 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : 5) k_trace(DScene 
         // x of column c: the row's running sum x += xstep (main.cpp:355-357), continued from the
         // stored value at the previous multiple of 8
         const int CK = (W + kXStride - 1) / kXStride;
-        x = xs[((size_t)b * H + r) * CK + c / kXStride];
-        for (int i = c & (kXStride - 1); i > 0; --i) x += xstep;
+        if (S.flags & 4u) {
+            x = (double)c / (double)W;  // light_tracing.cpp:787
+        } else {
+            x = xs[((size_t)b * H + r) * CK + c / kXStride];
+            for (int i = c & (kXStride - 1); i > 0; --i) x += xstep;
+        }
         y = ys[(size_t)b * H + r];
         dr.rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
 #ifdef PT_PROFILE_SECTIONS
@@ -474,7 +489,7 @@ struct pt_scene {
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
     DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_order;
-    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins, d_scan_rects;
+    DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins, d_scan_rects, d_scan_rects_mt;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
     DevBuf d_xs[2], d_ys[2], d_rowstart[2], d_npix[2], d_samples[2], d_accum;
@@ -557,6 +572,7 @@ struct SceneUpload {
     std::vector<DGeom> geom;
     std::vector<DMat> mat;
     std::vector<DRect> rects;
+    std::vector<DRectMT> rects_mt;
     std::vector<DGeom> scan_planes, scan_spheres;
     std::vector<DScreen2> scan_screen, scan_screen0;
     std::vector<char> in_slab;
@@ -608,6 +624,24 @@ struct SceneUpload {
                 }
                 r.body = i;
                 rects.push_back(r);
+            } else if (b.shape == PT_RECTANGLE_MT) {
+                // Rectangle ctor light_tracing.cpp:484-495; pt_body_construct has stored the normal
+                g.shape = kRectMT;
+                g.nx = b.normal[0];
+                g.ny = b.normal[1];
+                g.nz = b.normal[2];
+                g.pad[0] = (int32_t)rects_mt.size();
+                DRectMT r;
+                memset(&r, 0, sizeof r);
+                const double* c = b.corners;
+                for (int k = 0; k < 3; ++k) {
+                    r.p1[k] = c[k];
+                    r.e1[k] = c[3 + k] - c[k];
+                    r.e2[k] = c[6 + k] - c[k];
+                    r.e3[k] = c[9 + k] - c[k];
+                }
+                r.body = i;
+                rects_mt.push_back(r);
             } else if (b.shape == PT_PLANE) {
                 g.nx = b.normal[0];
                 g.ny = b.normal[1];
@@ -679,7 +713,7 @@ struct SceneUpload {
             g.pad[0] = i;
             if (g.shape == kSphere) {
                 scan_spheres.push_back(g);
-            } else if (g.shape != kRect) {
+            } else if (g.shape != kRect && g.shape != kRectMT) {
                 if (!in_slab[i]) scan_planes.push_back(g);
             }
         }
@@ -926,6 +960,21 @@ struct SceneUpload {
             HIP_TRY(hipMemcpy(s->d_scan_rects.p, rects.data(), sizeof(DRect) * rects.size(), hipMemcpyHostToDevice));
             D.scan_rects = (const DRect*)s->d_scan_rects.p;
         }
+        D.n_rects_mt = (int)rects_mt.size();
+        if (!rects_mt.empty()) {
+            int rcr = s->d_scan_rects_mt.ensure(sizeof(DRectMT) * rects_mt.size());
+            if (rcr) return rcr;
+            HIP_TRY(hipMemcpy(s->d_scan_rects_mt.p, rects_mt.data(), sizeof(DRectMT) * rects_mt.size(), hipMemcpyHostToDevice));
+            D.scan_rects_mt = (const DRectMT*)s->d_scan_rects_mt.p;
+        }
+        {
+            // det > -EPSILON && det < EPSILON, EPSILON = 0.000001L (light_tracing.cpp:20,542): for a double
+            // det that is |det| < e with e the smallest double not below the literal
+            const long double lit = 0.000001L;
+            double e = (double)lit;
+            if ((long double)e < lit) e = std::nextafter(e, INFINITY);
+            D.mt_eps = e;
+        }
         if (s->has_measured) {
             // Bin edges of the table indices (MatusikBRDF.h:211-257) as thresholds, descending:
             // theta_half bin k starts at (k/90)^2 pi/2 and theta_diff bin k at k pi/180 (cosines),
@@ -1127,15 +1176,15 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     s->bodies.assign(desc->bodies, desc->bodies + desc->body_count);
     for (size_t i = 0; i < s->bodies.size(); ++i) {
         pt_body& b = s->bodies[i];
-        if (b.shape != PT_SPHERE && b.shape != PT_PLANE && b.shape != PT_RECTANGLE) {
+        if (b.shape != PT_SPHERE && b.shape != PT_PLANE && b.shape != PT_RECTANGLE && b.shape != PT_RECTANGLE_MT) {
             delete s;
             return fail(PT_ERR_INVALID, "pt_scene_create: unknown shape");
         }
-        if (b.shape == PT_RECTANGLE) {
+        if (b.shape == PT_RECTANGLE || b.shape == PT_RECTANGLE_MT) {
             s->has_rectangles = true;
             if (s->estimator != PT_EST_PT) {
                 delete s;
-                return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: rectangles exist only in raytrace3.cpp's path tracer (PT_EST_PT)");
+                return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: rectangles exist only under plain path tracing (PT_EST_PT)");
             }
         }
         if (b.material < PT_DIFFUSE || b.material > PT_MEASURED) {
@@ -1158,6 +1207,8 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     // Loop steps of Renderer::iterate: double xstep = 1.0L / (double)width (main.cpp:352,355)
     s->xstep = (double)(1.0L / (long double)(double)s->width);
     s->ystep = (double)(1.0L / (long double)(double)s->height);
+    s->part.row_lo = 0;
+    s->part.row_hi = s->height;
     int rc = setup_partition(s, 0, 1, 32, 8);
     if (rc == PT_OK) rc = upload_scene(s);
     if (rc != PT_OK) {
@@ -1183,6 +1234,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_scan_screen0.release();
     s->d_brdf_bins.release();
     s->d_scan_rects.release();
+    s->d_scan_rects_mt.release();
     s->d_lights.release();
     for (auto& b : s->d_brdf) b.release();
     for (int k = 0; k < 2; ++k) {
@@ -1257,6 +1309,15 @@ int pt_brdf_load_file(pt_scene* s, int id, const char* path) {
 int pt_set_partition(pt_scene* s, int rank, int world, int tile_w, int tile_h) {
     if (!s) return fail(PT_ERR_INVALID, "null scene");
     return setup_partition(s, rank, world, tile_w, tile_h);
+}
+
+int pt_set_rows(pt_scene* s, int start_row, int row_count) {
+    if (!s) return fail(PT_ERR_INVALID, "null scene");
+    if (start_row < 0 || row_count < 0 || (int64_t)start_row + row_count > s->height)
+        return fail(PT_ERR_INVALID, "pt_set_rows: rows outside the frame");
+    s->part.row_lo = start_row;
+    s->part.row_hi = start_row + row_count;
+    return PT_OK;
 }
 
 int pt_tiles_per_rank(const pt_scene* s, int world) {
@@ -1339,7 +1400,7 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         }
         hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, s->st_layout, s->seed, W, H,
                            first_iteration + k * batch, s->xstep, s->ystep, (double*)s->d_xs[q].p, (double*)s->d_ys[q].p,
-                           (int32_t*)s->d_rowstart[q].p, (int32_t*)s->d_npix[q].p);
+                           (int32_t*)s->d_rowstart[q].p, (int32_t*)s->d_npix[q].p, (int)(s->flags & PT_F_PIXEL_GRID));
         HIP_TRY(hipEventRecord(s->ev_layout[q], s->st_layout));
         return PT_OK;
     };
@@ -1391,7 +1452,8 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     for (int q = 0; q < P.owned_tiles; ++q) {
         const int tile = q * P.world + P.rank;
         const int x0 = (tile % P.tiles_x) * P.tile_w, y0 = (tile / P.tiles_x) * P.tile_h;
-        owned_pixels += (double)std::max(0, std::min(P.tile_w, W - x0)) * (double)std::max(0, std::min(P.tile_h, H - y0));
+        const int y1 = std::min(std::min(y0 + P.tile_h, H), P.row_hi), y00 = std::max(y0, P.row_lo);
+        owned_pixels += (double)std::max(0, std::min(P.tile_w, W - x0)) * (double)std::max(0, y1 - y00);
     }
     s->last_paths = (double)n_iterations * owned_pixels;
     return PT_OK;
@@ -1454,7 +1516,7 @@ int pt_render_device_noalloc(pt_scene* s, int first_iteration, int n_iterations,
     for (int it0 = first_iteration, left = n_iterations; left > 0; it0 += batch, left -= batch) {
         const int B = std::min(batch, left);
         hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, st, s->seed, W, H, it0, s->xstep, s->ystep, xs, ys,
-                           rs, npix);
+                           rs, npix, (int)(s->flags & PT_F_PIXEL_GRID));
         dim3 grid(P.owned_tiles, B);
         if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
             hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
@@ -1590,7 +1652,8 @@ int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t*
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const int CK = (W + kXStride - 1) / kXStride;
     hipLaunchKernelGGL(k_frame_layout, dim3(1), dim3(layout_threads), 0, 0, s->seed, W, H, iteration, s->xstep, s->ystep,
-                       (double*)s->d_xs[0].p, (double*)s->d_ys[0].p, (int32_t*)s->d_rowstart[0].p, (int32_t*)s->d_npix[0].p);
+                       (double*)s->d_xs[0].p, (double*)s->d_ys[0].p, (int32_t*)s->d_rowstart[0].p, (int32_t*)s->d_npix[0].p,
+                       (int)(s->flags & PT_F_PIXEL_GRID));
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> rs(H + 1);
     std::vector<double> ck((size_t)H * CK);
@@ -1605,6 +1668,7 @@ int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t*
         for (int c = 0; c < row_len[r]; ++c) {
             volatile double x = ck[(size_t)r * CK + c / kXStride];
             for (int i = c & (kXStride - 1); i > 0; --i) x = x + s->xstep;
+            if (s->flags & PT_F_PIXEL_GRID) x = (double)c / (double)W;
             xs[(size_t)r * W + c] = x;
         }
     }

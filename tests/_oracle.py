@@ -17,7 +17,7 @@ REF_HOOKED_SO = os.path.join(ROOT, "oracle", "_ref", "libptref_hooked.so")
 
 MODE_SEQ, MODE_SCRIPT, MODE_PIXEL = 0, 1, 2
 EST_PT, EST_NEE = 0, 1
-SPHERE, PLANE, RECTANGLE = 0, 1, 2
+SPHERE, PLANE, RECTANGLE, RECTANGLE_MT = 0, 1, 2, 3
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3
 RAND_MAX = 2147483647
 BRDF_N = 90 * 90 * 180
@@ -159,6 +159,21 @@ class Port:
             C.byref(s), mode, first_it, n_it, _p(sc) if sc is not None else None, len(sc) if sc is not None else 0, _p(accum)
         )
         return accum, draws
+
+    def render_rows(self, s, start_row, row_count, first_it, n_it, accum=None):
+        """ray_iterate(start_row, row_count) (light_tracing.cpp:774-790), n_it passes."""
+        if accum is None:
+            accum = np.zeros((s.height, s.width, 3), dtype=np.float64)
+        self.lib.por_render_rows(C.byref(s), int(start_row), int(row_count), int(first_it), int(n_it), _p(accum))
+        return accum
+
+    def row_split(self, height, workers):
+        out = []
+        for i in range(workers):
+            a, b = C.c_int(), C.c_int()
+            self.lib.por_row_split(int(height), int(workers), i, C.byref(a), C.byref(b))
+            out.append((a.value, b.value))
+        return out
 
     def frame_layout(self, s, it):
         ys = np.full(s.height, np.nan)
@@ -377,7 +392,7 @@ def constructed(port, bodies, n):
             nn = port.plane_normal(np.array(list(bodies[i].normal)))
             for k in range(3):
                 out[i].normal[k] = nn[k]
-        if out[i].shape == RECTANGLE:  # normal = normalize((p3-p1) x (p2-p1)), raytrace3.cpp:260
+        if out[i].shape in (RECTANGLE, RECTANGLE_MT):  # normal = normalize((p3-p1) x (p2-p1)), raytrace3.cpp:260, light_tracing.cpp:494
             nn = port.rect_normal(np.array(list(bodies[i].corners)))
             for k in range(3):
                 out[i].normal[k] = nn[k]

@@ -115,3 +115,22 @@ def rectangle_scene(seed, W, H, n_rect=7, n_sphere=5, n_plane=2):
     d.body_count = n
     d._keep = bodies
     return d
+
+
+def mt_rectangle_scene(seed, W, H, n_rect=7, n_sphere=5, n_plane=2, grid=True, warp=0.0):
+    """rectangle_scene with the rectangles as light_tracing.cpp's Moller-Trumbore kind, hit threshold
+    t > 0, and (grid) samples on the pixel grid.  warp > 0 lifts every fourth corner off the plane of
+    the other three, so that the two triangles of a rectangle are not coplanar."""
+    import numpy as np
+
+    d = rectangle_scene(seed, W, H, n_rect=n_rect, n_sphere=n_sphere, n_plane=n_plane)
+    rng = np.random.default_rng(9000 + seed)
+    for i in range(d.body_count):
+        b = d.bodies[i]
+        if b.shape == pt.RECTANGLE:
+            b.shape = pt.RECTANGLE_MT
+            if warp > 0.0:
+                for c in range(3):
+                    b.corners[9 + c] += float(rng.normal() * warp)
+    d.flags = pt.F_PIXEL_GRID if grid else 0
+    return d
