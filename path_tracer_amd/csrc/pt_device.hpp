@@ -647,24 +647,44 @@ PTD_INLINE int nearest_hit_shadow(const DScene& S, V3 lc, V3 d, int light, doubl
 // getRandomNormalInHemisphere main.cpp:105-117.  Draw order z, y, x (g++ evaluates the
 // constructor arguments right to left); the normalised copy is discarded by the reference.
 // The rejection test dot(v,v) > 1.0 is first screened in float: a candidate whose float length
-// is outside 1 +- 1e-5 is decided without forming the doubles (the float evaluation is within
-// 2.5e-6 of the exact value); only candidates inside that shell take the exact FP64 test.  The
-// accepted triple is then converted once.  Decisions and results are identical to the plain loop.
+// is outside 1 +- 1e-5 is decided without forming the doubles; only candidates inside that shell
+// take the exact FP64 test.  The accepted triple is then converted once.  Decisions and results are
+// identical to the plain loop.
+// The float coordinate of a draw comes straight from the generator's 32-bit sum s (the draw is
+// k = s >> 1): the top 23 bits of s become the mantissa of a float in [2, 4), f = 2 + (s >> 9) 2^-22,
+// and f - 3 is exact.  Against the exact coordinate 2 k / (2^31 - 1) - 1 it is low by less than
+// 2^-22 + 2^-30, so the squared length differs by less than 3 * 2 * 2.4e-7 = 1.5e-6, plus 5.4e-7 of
+// float rounding in the three squares and two sums: 2.0e-6, well inside the shell's 1e-5.
+PTD_INLINE uint32_t rng_next_sum(Rng& r) {  // the 32-bit sum whose upper 31 bits are the draw
+    uint32_t result = r.s0 + r.s3;
+    uint32_t t = r.s1 << 9;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = (r.s3 << 11) | (r.s3 >> 21);
+    return result;
+}
+PTD_INLINE float sum_to_coord(uint32_t s) {
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x80u, s, 9u)) - 3.0f;  // 0x40000000 | (s >> 9)
+}
 PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
-    int32_t kz, ky, kx;
+    uint32_t sz, sy, sx;
     for (;;) {
-        kz = rng_next(dr.rng);
-        ky = rng_next(dr.rng);
-        kx = rng_next(dr.rng);
+        sz = rng_next_sum(dr.rng);
+        sy = rng_next_sum(dr.rng);
+        sx = rng_next_sum(dr.rng);
         dr.count += 3;
-        const float sc = 2.0f / 2147483647.0f;
-        float fz = (float)kz * sc - 1.0f, fy = (float)ky * sc - 1.0f, fx = (float)kx * sc - 1.0f;
+        float fz = sum_to_coord(sz), fy = sum_to_coord(sy), fx = sum_to_coord(sx);
         float s2 = fx * fx + fy * fy + fz * fz;
         if (s2 > 1.00001f) continue;
         if (s2 < 0.99999f) break;
+        const int32_t kz = (int32_t)(sz >> 1), ky = (int32_t)(sy >> 1), kx = (int32_t)(sx >> 1);
         V3 e = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
         if (!(dot(e, e) > 1.0)) break;
     }
+    const int32_t kz = (int32_t)(sz >> 1), ky = (int32_t)(sy >> 1), kx = (int32_t)(sx >> 1);
     V3 v = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
     if (dot(v, n) < 0.0) v = muls(v, -1.0);
     return v;
