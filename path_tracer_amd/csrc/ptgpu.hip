@@ -59,18 +59,21 @@ constexpr int kXStride = 8;  // the x running sum of a row is stored at every 8t
 
 struct Partition {
     int rank, world;
-    int tile_w, tile_h;
+    int tile_w, tile_h;  // tile_w * tile_h == 256, so both are powers of two
+    int tile_w_log2;
     int tiles_x, tiles_y;
     int owned_tiles;
     int row_lo, row_hi;  // destination rows [row_lo, row_hi) of pt_set_rows (0, height by default)
 };
 
-// Destination slot of thread `tid` in owned tile `q`, or -1 outside the image or the row range.
-PTD_INLINE int slot_of(const Partition& P, int q, int tid, int W, int H) {
+// Destination slot of thread `tid` in owned tile `q`, or -1 outside the image or the row range;
+// *row_out (optional) receives the destination row.
+PTD_INLINE int slot_of(const Partition& P, int q, int tid, int W, int H, int* row_out = nullptr) {
     int tile = q * P.world + P.rank;
     int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    int px = tx * P.tile_w + tid % P.tile_w;
-    int py = ty * P.tile_h + tid / P.tile_w;
+    int px = tx * P.tile_w + (tid & (P.tile_w - 1));
+    int py = ty * P.tile_h + (tid >> P.tile_w_log2);
+    if (row_out) *row_out = py;
     if (px >= W || py >= H || py < P.row_lo || py >= P.row_hi) return -1;
     return py * W + px;
 }
@@ -172,7 +175,8 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : 5) k_trace(DScene 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int W = S.width, H = S.height;
-    const int slot = slot_of(P, blockIdx.x, tid, W, H);
+    int dest_row;
+    const int slot = slot_of(P, blockIdx.x, tid, W, H, &dest_row);
     const size_t j = (size_t)blockIdx.x * kBlock + tid;
     double* out = samples + (size_t)b * 3 * sample_stride + j;
     V3 rgb = mk(0.0, 0.0, 0.0);
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : 5) k_trace(DScene 
         long long t_setup = __builtin_amdgcn_s_memtime();
 #endif
         const int32_t* rs = row_start + (size_t)b * (H + 1);
-        int r = slot / W;
+        int r = dest_row;  // == slot / W; short rows before it can only move the source row down
         while (slot >= rs[r + 1]) r++;
         int c = slot - rs[r];
         // x of column c: the row's running sum x += xstep (main.cpp:355-357), continued from the
@@ -520,6 +524,8 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     P.world = world;
     P.tile_w = tw;
     P.tile_h = th;
+    P.tile_w_log2 = 0;
+    while ((1 << P.tile_w_log2) < tw) P.tile_w_log2++;
     P.tiles_x = (s->width + tw - 1) / tw;
     P.tiles_y = (s->height + th - 1) / th;
     int total = P.tiles_x * P.tiles_y;
