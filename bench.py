@@ -301,7 +301,29 @@ def main():
                 "paths_per_launch": paths_per_launch,
                 "flop_per_path": flop_per_path,
             }
-            if pmc and pmc.get("fp64_flop_per_path"):
+            if wavefront:
+                # The stages of the wavefront pipeline answer almost every body test of a 10 000-body scan in
+                # float (bounding groups, member screens), so FP64 flops are the wrong yardstick.  The bound
+                # claimed is VALU issue: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
+                out["roofline"]["brute_force_equivalent_TFLOPs"] = achieved
+                peak_issue = 1024 * 2.4e9 / 4.0 / 1e9  # G wave-instructions per second
+                if pmc and pmc.get("valu_wave_insts_per_path"):
+                    rate = (paths / elapsed) * pmc["valu_wave_insts_per_path"] / 1e9
+                    out["roofline"].update({
+                        "bound": "valu_issue", "achieved": rate, "peak": peak_issue, "unit": "G wave-instr/s",
+                        "frac": rate / peak_issue, "frac_of_no_fma_ceiling": None,
+                        "valu_wave_insts_per_path": pmc["valu_wave_insts_per_path"],
+                        "active_lanes_of_64": pmc.get("active_lanes"),
+                        "fp64_share_of_valu_issue": pmc.get("fp64_share_of_valu_issue"),
+                        "source": pmc.get("source"),
+                        "note": "VALU instructions issued per path (counter passes of the same workload) times the "
+                                "measured whole-pipeline path rate, against the VALU issue peak; "
+                                "brute_force_equivalent_TFLOPs prices every body test of every scan at its FP64 cost",
+                    })
+                else:
+                    out["roofline"].update({"bound": "valu_issue", "achieved": None, "peak": peak_issue,
+                                            "unit": "G wave-instr/s", "frac": None, "frac_of_no_fma_ceiling": None})
+            if pmc and pmc.get("fp64_flop_per_path") and not wavefront:
                 # what the FP64 units really executed (counter passes of the same kernel), at this run's rate
                 rate = paths_per_launch / (avg_ms * 1e-3)
                 ex = rate * pmc["fp64_flop_per_path"] / 1e12

@@ -61,10 +61,42 @@ def summary(root):
     return out
 
 
+def sums(root, pat):
+    """Counter totals over every dispatch whose kernel name contains `pat`."""
+    tot = defaultdict(float)
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if pat in row.get("Kernel_Name", ""):
+                    tot[row["Counter_Name"]] += float(row["Counter_Value"])
+    return tot
+
+
+def summary_pipeline(root, pat, paths):
+    """A pipeline of several kernels (the wavefront stages): totals over all of them, per path of the run."""
+    t = sums(root, pat)
+    valu = t["SQ_INSTS_VALU"]
+    fp64 = t["SQ_INSTS_VALU_ADD_F64"] + t["SQ_INSTS_VALU_MUL_F64"] + t["SQ_INSTS_VALU_FMA_F64"] + t["SQ_INSTS_VALU_TRANS_F64"]
+    flop_insts = fp64 + t["SQ_INSTS_VALU_FMA_F64"]
+    lanes = t["SQ_THREAD_CYCLES_VALU"] / valu
+    return {
+        "source": f"rocprofv3 --pmc passes of scripts/pmc.sh ({os.path.basename(root.rstrip('/'))}), all {pat}* kernels of a run of {int(paths)} paths",
+        "valu_wave_insts_per_path": valu / paths,  # wave instructions (64 lanes each) issued per path
+        "active_lanes": lanes,
+        "fp64_share_of_valu_issue": fp64 / valu,
+        "fp64_flop_per_path": flop_insts * lanes / paths,
+        "waves_per_path": t["SQ_WAVES"] / paths,
+    }
+
+
 def main():
     res = {}
     for arg in sys.argv[1:]:
         scene, root = arg.split("=", 1)
+        if root.count(":") == 2:  # dir:kernel-pattern:paths
+            d, pat, paths = root.split(":")
+            res[scene] = summary_pipeline(d, pat, float(paths))
+            continue
         res[scene] = summary(root)
     json.dump(res, sys.stdout, indent=1)
     print()
