@@ -488,10 +488,12 @@ PTD_INLINE double sel64(lanemask m, double if_set, double if_clear) {
     uint32_t hi = sel32(m, (uint32_t)__double2hiint(if_set), (uint32_t)__double2hiint(if_clear));
     return __hiloint2double((int)hi, (int)lo);
 }
-// (t > 0) && ((t < mint) || (t == mint && i > hit)) && (i != skip), within `valid`
+// (t > 0) && ((t < mint) || (t == mint && i > hit)) && (i != skip), within `valid`.
+// HAS_SKIP false: the caller knows that no body is excluded (skip == -1), body indices being >= 0.
+template <bool HAS_SKIP>
 PTD_INLINE void merge_masked(lanemask valid, double t, int i, int skip, int& hit, double& mint) {
-    const lanemask take = valid & PTD_MASK(t > 0.0) & (PTD_MASK(t < mint) | (PTD_MASK(t == mint) & PTD_MASK(i > hit))) &
-                          PTD_MASK(i != skip);
+    lanemask take = valid & PTD_MASK(t > 0.0) & (PTD_MASK(t < mint) | (PTD_MASK(t == mint) & PTD_MASK(i > hit)));
+    if (HAS_SKIP) take &= PTD_MASK(i != skip);
     mint = sel64(take, t, mint);
     hit = (int)sel32(take, (uint32_t)i, (uint32_t)hit);
 }
@@ -503,6 +505,7 @@ PTD_INLINE void merge_masked(lanemask valid, double t, int i, int skip, int& hit
 // the same sign (`both`): the chosen plane is the excluded light, or the two quotients could
 // round to the same value (excluded by |o_k| < big, which keeps n_hi - n_lo above 2^-41 |n|).
 // Then (wave-uniform, rare) the second quotient is formed and merged as well.
+template <bool HAS_SKIP>
 PTD_INLINE void scan_slab(double lo, double hi, double big, int ilo, int ihi, double ok_, double dk, int skip, int& hit,
                           double& mint) {
     const double n_lo = lo - ok_, n_hi = hi - ok_;
@@ -512,16 +515,17 @@ PTD_INLINE void scan_slab(double lo, double hi, double big, int ilo, int ihi, do
     const lanemask valid = PTD_MASK(!(__builtin_fabs(dk) < 0.00001));  // == !((dk > -1e-5) && (dk < 1e-5))
     const int i = (int)sel32(pick_lo, (uint32_t)ilo, (uint32_t)ihi);
     const double t = sel64(pick_lo, n_lo, n_hi) / dk;
-    merge_masked(valid, t, i, skip, hit, mint);
-    const lanemask second = both & (PTD_MASK(i == skip) | ~PTD_MASK(__builtin_fabs(ok_) < big));
+    merge_masked<HAS_SKIP>(valid, t, i, skip, hit, mint);
+    lanemask second = both & ~PTD_MASK(__builtin_fabs(ok_) < big);
+    if (HAS_SKIP) second |= both & PTD_MASK(i == skip);
     if (second != 0) {
         const double t2 = sel64(pick_lo, n_hi, n_lo) / dk;
-        merge_masked(valid, t2, (int)sel32(pick_lo, (uint32_t)ihi, (uint32_t)ilo), skip, hit, mint);
+        merge_masked<HAS_SKIP>(valid, t2, (int)sel32(pick_lo, (uint32_t)ihi, (uint32_t)ilo), skip, hit, mint);
     }
 }
 // Steps 1 and 2 of the scan: the planes outside the slabs, then the slabs.  ORIGIN0: the ray starts
 // at exactly (0,0,0) — `o` must be that — and the origin-dependent terms come from the records.
-template <bool ORIGIN0>
+template <bool ORIGIN0, bool HAS_SKIP = true>
 PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ planes, V3 o, V3 d, int skip, int& hit,
                                 double& mint) {
     PT_PROF(kProfScanPlanes);
@@ -547,16 +551,16 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
                 break;
         }
         const int i = g.pad[0];
-        bool take = ok && (t > eps) && (t <= mint) && (i != skip);
+        bool take = ok && (t > eps) && (t <= mint) && (!HAS_SKIP || i != skip);
         mint = take ? t : mint;
         hit = take ? i : hit;
     }
     if (S.slab_mask & 1)
-        scan_slab(S.slab_lo[0], S.slab_hi[0], S.slab_big[0], S.slab_ilo[0], S.slab_ihi[0], o.x, d.x, skip, hit, mint);
+        scan_slab<HAS_SKIP>(S.slab_lo[0], S.slab_hi[0], S.slab_big[0], S.slab_ilo[0], S.slab_ihi[0], o.x, d.x, skip, hit, mint);
     if (S.slab_mask & 2)
-        scan_slab(S.slab_lo[1], S.slab_hi[1], S.slab_big[1], S.slab_ilo[1], S.slab_ihi[1], o.y, d.y, skip, hit, mint);
+        scan_slab<HAS_SKIP>(S.slab_lo[1], S.slab_hi[1], S.slab_big[1], S.slab_ilo[1], S.slab_ihi[1], o.y, d.y, skip, hit, mint);
     if (S.slab_mask & 4)
-        scan_slab(S.slab_lo[2], S.slab_hi[2], S.slab_big[2], S.slab_ilo[2], S.slab_ihi[2], o.z, d.z, skip, hit, mint);
+        scan_slab<HAS_SKIP>(S.slab_lo[2], S.slab_hi[2], S.slab_big[2], S.slab_ilo[2], S.slab_ihi[2], o.z, d.z, skip, hit, mint);
 }
 // Sphere::intersect from the origin (0,0,0): D = -c, c-term stored in the record.
 PTD_INLINE bool scan_sphere_exact_origin0(const DGeom& g, V3 d, double& t) {
@@ -583,12 +587,12 @@ PTD_INLINE void sphere_possible2_masks_origin0(float dx, float dy, float dz, flo
 }
 // RECTS: the scene may hold rectangles (plain path tracing only; the next-event kernels are built
 // without them).
-template <bool ORIGIN0, bool RECTS = false>
+template <bool ORIGIN0, bool RECTS = false, bool HAS_SKIP = true>
 PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ planes, const DGeom* __restrict__ spheres,
                                  const DScreen2* __restrict__ screen, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    scan_all_planes<ORIGIN0>(S, planes, o, d, skip, hit, mint);
+    scan_all_planes<ORIGIN0, HAS_SKIP>(S, planes, o, d, skip, hit, mint);
     if (RECTS) {
         const DRect* __restrict__ rects = S.scan_rects;
         const int n_rects = S.n_rects;
@@ -635,6 +639,11 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
 template <bool RECTS = false>
 PTD_INLINE int nearest_hit(const DScene& S, V3 o, V3 d, int skip, double& tmin) {
     return nearest_hit_lists<false, RECTS>(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, skip, tmin);
+}
+// The scan of a gather ray: no body is left out (main.cpp:372-383).
+template <bool RECTS = false>
+PTD_INLINE int nearest_hit_any(const DScene& S, V3 o, V3 d, double& tmin) {
+    return nearest_hit_lists<false, RECTS, false>(S, S.scan_planes, S.scan_spheres, S.scan_screen, o, d, -1, tmin);
 }
 // The scan of a shadow ray towards `d` with `light` left out (next_event.cpp:405-426).  Unless the
 // scene asks for the lights' real centres every shadow ray starts at (0,0,0).
@@ -1127,7 +1136,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
 #pragma unroll 1
     for (; n < kMaxDepth; ++n) {
         double mint;
-        int hit = nearest_hit<EST == kEstPT>(S, o, d, -1, mint);
+        int hit = nearest_hit_any<EST == kEstPT>(S, o, d, mint);
         if (hit < 0) break;
         V3 point = shade_hit(geom[hit], mat[hit], dr, o, d, mint);
         PT_PROF(kProfRecords);
@@ -1201,7 +1210,7 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
 #pragma unroll 1
         for (; n < kMaxDepth; ++n) {
             double mint;
-            int hit = nearest_hit(S, o, d, -1, mint);
+            int hit = nearest_hit_any(S, o, d, mint);
             if (hit < 0) break;
             const DMat& m = S.mat[hit];
             V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);  // o = point on return

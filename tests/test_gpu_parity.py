@@ -330,6 +330,22 @@ def test_wavefront_equals_fused_and_oracle(port, name, W, H, n_it):
     r.close()
 
 
+@pytest.mark.parametrize("W,H,n_it,seed", [(70, 40, 3, 31), (33, 17, 5, 2), (64, 8, 2, 9)])
+def test_measured_scene_fused_equals_wavefront(W, H, n_it, seed):
+    """Measured materials in both pipelines: the fused kernel and the wavefront stages evaluate the
+    lit vertices with the same device code and must give the same bits, with the hash tables (any
+    misplaced lookup shows) and with partial waves."""
+    r = pt.Renderer(pt.preset("nee15_measured", W, H, seed=seed))
+    for k in range(4):
+        r.brdf_upload(k, pt.synthetic_brdf_table(k))
+    fused = r.render(1, n_it)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    wave = r.render(1, n_it)
+    assert same_bits(fused, wave)
+    assert np.count_nonzero(fused) > 0.9 * fused.size
+    r.close()
+
+
 @pytest.mark.parametrize("name", ["nee15", "main32"])
 def test_open_scene_paths_terminate(port, name):
     # only the floor plane and the spheres are kept (every other plane is infinite and would close the
