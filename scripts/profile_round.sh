@@ -15,3 +15,5 @@ timeout -k 10 200 python3 bench.py --no-cpu --scene nee15_measured --iterations 
 timeout -k 10 200 python3 bench.py --no-cpu --width 3840 --height 2160 --iterations 256 > $out/bench_nee15_4k.json 2>> $out/bench.err || exit 1
 timeout -k 10 300 python3 bench.py --no-cpu --scene synthetic10k --iterations 63 --steps 1 > $out/bench_synthetic10k.json 2>> $out/bench.err || exit 1
 ls $out $out/trace
+timeout -k 10 200 python3 bench.py --no-cpu --pipeline wavefront --iterations 240 > $out/bench_nee15_wavefront.json 2>> $out/bench.err || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu --scene light_room32 --iterations 720 > $out/bench_light_room32.json 2>> $out/bench.err || exit 1
