@@ -335,8 +335,28 @@ def main():
                     "active_lanes_of_64": pmc.get("active_lanes"),
                     "source": pmc.get("source"),
                 }
+            if not wavefront:
+                out["roofline"]["frac_kind"] = "algorithmic-equivalent (brute-force body tests at FP64 cost); executed.frac_of_peak is what the FP64 units did"
             if world > 1:
                 out["roofline"]["note"] += "; rank 0's kernel launches, per-GPU rate"
+            if world == 1 and as_configured and args.config == "C2":
+                # the same scene with the direct term live (light colour 1): every shadow scan and fake-BRDF
+                # bounce is executed, nothing is proven dead — the rate of the kernel family without the
+                # compact next-event form, measured on a short run beside the headline
+                lit = pt.Renderer(pt.preset("nee15_lit", W, H, seed=1))
+                lit_it = 240
+                acc2 = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+                lit.render_device(0, 21, acc2.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                lit.render_device(0, lit_it, acc2.data_ptr(), stream)
+                torch.cuda.synchronize()
+                lit_rate = float(W) * H * lit_it / (time.perf_counter() - t1)
+                lit.close()
+                out["config"]["direct_term_live"] = {
+                    "scene": "nee15_lit", "iterations": lit_it, "paths_per_s": lit_rate,
+                    "algorithmic_frac": lit_rate * flop_per_path / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                }
             if world == 1 and not args.no_cpu:
                 cb = cpu_baseline(desc, scene, W, H, [t for t in tables] if tables else None, args.cpu_seconds)
                 out["cpu_baseline"] = cb
