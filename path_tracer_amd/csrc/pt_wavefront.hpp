@@ -361,6 +361,26 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_sort_keys(DScene S, WfState W, 
     atomicAdd(&W.bins[key], 1u);
 }
 
+// Keys only, for every entry up to the capacity of the queue: entries past its count get the
+// largest 16-bit key and sort to the end (the library sort takes its size from the host, which does
+// not know the count).
+constexpr uint32_t kSortKeyBits = 16;
+template <int MODE>
+__global__ void __launch_bounds__(kWfBlock) k_wf_ray_keys(DScene S, WfState W, int qi, int gi, int cap) {
+    const int count = W.qcount[qi];
+    const int i = blockIdx.x * kWfBlock + threadIdx.x;
+    if (i >= cap) return;
+    uint32_t key = 0xFFFFu;
+    if (i < count) {
+        const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
+        V3 o, d;
+        int skip;
+        queue_ray<MODE>(S, W, p, gi, o, d, skip);
+        key = ray_key<MODE>(S, o, d);
+    }
+    W.keys[i] = key;
+}
+
 // Exclusive prefix sum of the kSortBins counters, one block of 1024 threads.
 __global__ void __launch_bounds__(1024) k_wf_sort_scan(WfState W) {
     __shared__ uint32_t s_part[1024];

@@ -11,6 +11,7 @@
 //   k_accumulate   : per destination pixel, adds the batch's samples in iteration order into
 //                    the caller's FP64 buffer (single writer, no atomics, deterministic).
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cfloat>
 #include <cmath>
@@ -511,6 +512,8 @@ struct pt_scene {
     int pipeline = PT_PIPELINE_AUTO;
     int wf_batch = 1;  // iterations per wavefront batch
     DevBuf d_wf;       // one allocation carved into the wavefront state arrays
+    DevBuf d_wf_sort;  // the ray sort: sorted keys (unused afterwards) and the library's temporary storage
+    size_t wf_sort_tmp_bytes = 0;
     ptw::WfState wf;
 };
 
@@ -1086,6 +1089,11 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.keys = (uint32_t*)(W.sorted + cap);
     W.bins = W.keys + cap;
     W.cap = cap;
+    // the ray sort (rocprim radix sort of 16-bit keys with the path ids as values)
+    size_t tmp = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, W.keys, W.keys, W.queue, W.sorted, cap, 0u, ptw::kSortKeyBits, (hipStream_t)0));
+    s->wf_sort_tmp_bytes = tmp;
+    if ((rc = s->d_wf_sort.ensure(cap * sizeof(uint32_t) + ((tmp + 255) & ~(size_t)255) + 256))) return rc;
     return PT_OK;
 }
 
@@ -1102,13 +1110,16 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     // leave k_wf_generate in pixel order)
     auto sorted_list = [&](int mode, int qi, int gi) -> const int32_t* {
         if (!s->wf_sort) return W.queue + (size_t)qi * W.cap;
-        (void)hipMemsetAsync(W.bins, 0, kSortBins * sizeof(uint32_t), st);  // errors surface at hipGetLastError below
+        const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
         if (mode == kGather)
-            hipLaunchKernelGGL((k_wf_sort_keys<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi);
+            hipLaunchKernelGGL((k_wf_ray_keys<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi, cap);
         else
-            hipLaunchKernelGGL((k_wf_sort_keys<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi);
-        hipLaunchKernelGGL(k_wf_sort_scan, dim3(1), dim3(1024), 0, st, W);
-        hipLaunchKernelGGL(k_wf_sort_scatter, dim3(nblk), dim3(kWfBlock), 0, st, W, qi);
+            hipLaunchKernelGGL((k_wf_ray_keys<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi, cap);
+        uint32_t* keys_out = (uint32_t*)s->d_wf_sort.p;
+        void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
+        size_t tmp_bytes = s->wf_sort_tmp_bytes;
+        (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, W.keys, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)cap, 0u,
+                                        kSortKeyBits, st);  // errors surface at hipGetLastError below
         return W.sorted;
     };
     for (int depth = 0; depth < kMaxDepth; ++depth) {
@@ -1258,6 +1269,7 @@ int pt_scene_destroy(pt_scene* s) {
     if (s->st_accum) (void)hipStreamDestroy(s->st_accum);
     s->d_accum.release();
     s->d_wf.release();
+    s->d_wf_sort.release();
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
     return PT_OK;
