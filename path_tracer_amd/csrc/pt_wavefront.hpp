@@ -38,9 +38,8 @@ struct WfState {
     int32_t* need;   // [cap]     1 + deepest emitting vertex (scenes with a dead direct term), else 0
     int32_t* queue;  // [11][cap] 0..5: paths with more than d-1 records; 6..10: shadow tasks of vertex 0..4
     int32_t* qcount; // [16]
-    int32_t* sorted; // [cap]     a queue reordered by ray key (see k_wf_sort_*)
+    int32_t* sorted; // [cap]     a queue reordered by ray key (see k_wf_ray_keys)
     uint32_t* keys;  // [cap]
-    uint32_t* bins;  // [kSortBins] histogram, then running offsets
     size_t cap;
 };
 
@@ -285,8 +284,6 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
 enum { kGather = 0, kShadow = 1 };
 
 
-constexpr int kSortBins = 1 << 16;
-
 // The ray of entry i of queue qi: the path's current ray, or the shadow ray towards vertex gi.
 template <int MODE>
 PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V3& o, V3& d, int& skip) {
@@ -306,16 +303,27 @@ PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V
 
 // Rays are reordered before a scan so that the 64 rays of a wave start near one another and
 // point the same way: a wave then enters few of the body groups.  The key is a cell of the
-// direction (cube face, 8x8; the major part: measured to matter more) and a coarse cell of the
-// origin (5x5x5 over the scene's box); shadow rays, which share their origin, use a fine
-// direction cell (cube face, 64x64).  One counting sort per
-// scan: histogram, exclusive scan, scatter.  The order inside a bin is arbitrary and, like the
-// order of a queue, invisible in the results.
+// direction (cube face, 4x4) and a cell of the origin (8x8x8 over the box of the sphere centres);
+// shadow rays, which share their origin, use a fine direction cell (cube face, 64x64).  (Measured
+// on the 10 000-body scene: 8x8 / 5^3 2.48e8, 8x8 / 8^3 2.57e8, 16x16 / 8^3 2.29e8, 4x4 / 8^3 2.71e8,
+// 3x3 / 10^3 2.72e8, 2x2 / 12^3 2.68e8, faces only / 16^3 2.54e8 paths/s.)  One radix sort of the
+// 16-bit keys per scan (rocprim, path ids as values; stable, so a bin keeps the queue's order).  The
+// order of a queue is invisible in the results.
 PTD_INLINE uint32_t grid_cell(float u, int cells) {  // u in [-1, 1] -> 0..cells-1, NaN -> 0
     int c = (int)((u + 1.0f) * (0.5f * (float)cells));
     c = c < cells - 1 ? c : cells - 1;
     return (uint32_t)(c > 0 ? c : 0);
 }
+#ifndef PT_KEY_D
+#define PT_KEY_D 4
+#endif
+#ifndef PT_KEY_O
+#define PT_KEY_O 8
+#endif
+#ifndef PT_KEY_BITS
+#define PT_KEY_BITS 16
+#endif
+constexpr int kKeyDir = PT_KEY_D, kKeyOrg = PT_KEY_O;
 template <int MODE>
 PTD_INLINE uint32_t ray_key(const DScene& S, V3 o, V3 d) {
     const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
@@ -340,37 +348,24 @@ PTD_INLINE uint32_t ray_key(const DScene& S, V3 o, V3 d) {
     }
     const float inv = m > 0.0f ? 1.0f / m : 0.0f;
     if (MODE == kShadow) return (face * 64u + grid_cell(v * inv, 64)) * 64u + grid_cell(u * inv, 64);  // < 24576
-    const uint32_t dir = (face * 8u + grid_cell(v * inv, 8)) * 8u + grid_cell(u * inv, 8);  // < 384
-    const uint32_t cx = grid_cell(((float)o.x - S.sort_mid[0]) * S.sort_inv[0], 5);
-    const uint32_t cy = grid_cell(((float)o.y - S.sort_mid[1]) * S.sort_inv[1], 5);
-    const uint32_t cz = grid_cell(((float)o.z - S.sort_mid[2]) * S.sort_inv[2], 5);
-    return (dir << 7) | ((cz * 5u + cy) * 5u + cx);  // < 49152
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(kWfBlock) k_wf_sort_keys(DScene S, WfState W, int qi, int gi) {
-    const int count = W.qcount[qi];
-    const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if (i >= count) return;
-    const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
-    V3 o, d;
-    int skip;
-    queue_ray<MODE>(S, W, p, gi, o, d, skip);
-    const uint32_t key = ray_key<MODE>(S, o, d);
-    W.keys[i] = key;
-    atomicAdd(&W.bins[key], 1u);
+    const uint32_t dir = (face * kKeyDir + grid_cell(v * inv, kKeyDir)) * kKeyDir + grid_cell(u * inv, kKeyDir);
+    const uint32_t cx = grid_cell(((float)o.x - S.sort_mid[0]) * S.sort_inv[0], kKeyOrg);
+    const uint32_t cy = grid_cell(((float)o.y - S.sort_mid[1]) * S.sort_inv[1], kKeyOrg);
+    const uint32_t cz = grid_cell(((float)o.z - S.sort_mid[2]) * S.sort_inv[2], kKeyOrg);
+    return dir * (kKeyOrg * kKeyOrg * kKeyOrg) + ((cz * kKeyOrg + cy) * kKeyOrg + cx);
 }
 
 // Keys only, for every entry up to the capacity of the queue: entries past its count get the
 // largest 16-bit key and sort to the end (the library sort takes its size from the host, which does
 // not know the count).
-constexpr uint32_t kSortKeyBits = 16;
+constexpr uint32_t kSortKeyBits = PT_KEY_BITS;
+static_assert(6ull * PT_KEY_D * PT_KEY_D * PT_KEY_O * PT_KEY_O * PT_KEY_O < (1ull << PT_KEY_BITS) - 1, "gather keys must stay below the end key");
 template <int MODE>
 __global__ void __launch_bounds__(kWfBlock) k_wf_ray_keys(DScene S, WfState W, int qi, int gi, int cap) {
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
     if (i >= cap) return;
-    uint32_t key = 0xFFFFu;
+    uint32_t key = (1u << kSortKeyBits) - 1u;
     if (i < count) {
         const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
         V3 o, d;
@@ -379,40 +374,6 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_ray_keys(DScene S, WfState W, i
         key = ray_key<MODE>(S, o, d);
     }
     W.keys[i] = key;
-}
-
-// Exclusive prefix sum of the kSortBins counters, one block of 1024 threads.
-__global__ void __launch_bounds__(1024) k_wf_sort_scan(WfState W) {
-    __shared__ uint32_t s_part[1024];
-    constexpr int kPer = kSortBins / 1024;
-    const int t = threadIdx.x;
-    uint32_t local[kPer];
-    uint32_t sum = 0;
-    for (int k = 0; k < kPer; ++k) {
-        local[k] = W.bins[t * kPer + k];
-        sum += local[k];
-    }
-    s_part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = t >= off ? s_part[t - off] : 0u;
-        __syncthreads();
-        s_part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[t] - sum;
-    for (int k = 0; k < kPer; ++k) {
-        W.bins[t * kPer + k] = run;
-        run += local[k];
-    }
-}
-
-__global__ void __launch_bounds__(kWfBlock) k_wf_sort_scatter(WfState W, int qi) {
-    const int count = W.qcount[qi];
-    const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t pos = atomicAdd(&W.bins[W.keys[i]], 1u);
-    W.sorted[pos] = W.queue[(size_t)qi * W.cap + i];
 }
 
 // One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.

@@ -1064,8 +1064,8 @@ int ensure_wavefront_buffers(pt_scene* s) {
     const size_t cap = J * (size_t)s->wf_batch;
     if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
     // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, need 1,
-    // queue 11, sorted 1, keys 1 = 26; plus the 16 queue counters and the kSortBins sort counters
-    size_t bytes = cap * (27 * sizeof(double) + 26 * sizeof(int32_t)) + (16 + ptw::kSortBins) * sizeof(int32_t);
+    // queue 11, sorted 1, keys 1 = 26; plus the 16 queue counters
+    size_t bytes = cap * (27 * sizeof(double) + 26 * sizeof(int32_t)) + 16 * sizeof(int32_t);
     int rc = s->d_wf.ensure(bytes);
     if (rc) return rc;
     ptw::WfState& W = s->wf;
@@ -1087,7 +1087,6 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.qcount = W.queue + 11 * cap;
     W.sorted = W.qcount + 16;
     W.keys = (uint32_t*)(W.sorted + cap);
-    W.bins = W.keys + cap;
     W.cap = cap;
     // the ray sort (rocprim radix sort of 16-bit keys with the path ids as values)
     size_t tmp = 0;
