@@ -43,26 +43,29 @@ struct WfState {
     size_t cap;
 };
 
-// Append `value` for every thread with `pred` set: one atomic per block (the four waves' counts
-// meet in LDS).  Every thread of a kWfBlock-thread block must call it; `slots` is two words of LDS
-// per wave.  The order of a queue is arbitrary; no result depends on it.
+// Append `value` for every thread with `pred` set: one atomic per block (the waves' counts meet in
+// LDS).  Atomics on one counter retire at about one per 9 ns, which is what a push costs: the
+// shading stages therefore run blocks of kPushBlock threads, a quarter of the atomics of 256-thread
+// blocks.  Every thread of the block must call it; `slots` is blockDim.x / 64 + 1 words of LDS.  The
+// order of a queue is arbitrary; no result depends on it.
+constexpr int kPushBlock = 1024;
 PTD_INLINE void queue_push(int32_t* q, int32_t* count, bool pred, int value, int32_t* slots) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (int)(blockDim.x >> 6);
     __syncthreads();  // `slots` may still be read from the previous push
     if (lane == 0) slots[wave] = (int)__builtin_popcountll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         int total = 0;
-        for (int w = 0; w < kWfBlock / 64; ++w) {
+        for (int w = 0; w < nwaves; ++w) {
             const int c = slots[w];
             slots[w] = total;  // exclusive prefix inside the block
             total += c;
         }
-        slots[kWfBlock / 64] = total ? atomicAdd(count, total) : 0;
+        slots[nwaves] = total ? atomicAdd(count, total) : 0;
     }
     __syncthreads();
-    if (pred) q[slots[kWfBlock / 64] + slots[wave] + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = value;
+    if (pred) q[slots[nwaves] + slots[wave] + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = value;
 }
 
 PTD_INLINE Rng load_rng(const WfState& W, size_t p) {
@@ -400,10 +403,10 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int
 }
 
 // Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.
-__global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int qi, int depth) {
+__global__ void __launch_bounds__(kPushBlock) k_wf_shade(DScene S, WfState W, int qi, int depth) {
     const int count = W.qcount[qi];
-    const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if ((int)(blockIdx.x * kWfBlock) >= count) return;
+    const int i = blockIdx.x * kPushBlock + threadIdx.x;
+    if ((int)(blockIdx.x * kPushBlock) >= count) return;
     bool alive = false;
     size_t p = 0;
     if (i < count) {
@@ -428,7 +431,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DScene S, WfState W, int 
             store_rng(W, p, dr.rng);
         }
     }
-    __shared__ int32_t s_push[kWfBlock / 64 + 1];
+    __shared__ int32_t s_push[kPushBlock / 64 + 1];
     queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
 }
 
@@ -438,10 +441,10 @@ constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks
 // In a scene whose direct term is dead (DScene::nee_emission_only) the colour recurrence starts at
 // zero and stays there until the deepest emitting vertex, so only vertices 0..need-1 get a shadow
 // ray; otherwise every recorded vertex does.
-__global__ void __launch_bounds__(kWfBlock) k_wf_light(DScene S, WfState W) {
+__global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
     const int count = W.qcount[0];
-    const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if ((int)(blockIdx.x * kWfBlock) >= count) return;
+    const int i = blockIdx.x * kPushBlock + threadIdx.x;
+    if ((int)(blockIdx.x * kPushBlock) >= count) return;
     const bool active = i < count;
     size_t p = 0;
     int tasks = 0;
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_light(DScene S, WfState W) {
         store_rng(W, p, dr.rng);
         tasks = S.nee_emission_only ? W.need[p] : W.nrec[p];
     }
-    __shared__ int32_t s_push[kWfBlock / 64 + 1];
+    __shared__ int32_t s_push[kPushBlock / 64 + 1];
     for (int g = 0; g < kMaxDepth; ++g)
         queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, tasks > g, (int)p, s_push);
 }

@@ -1103,6 +1103,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const WfState W = s->wf;
     const Partition P = s->part;
     const int nblk = (int)((J * (size_t)B + kWfBlock - 1) / kWfBlock);
+    const int nblk_push = (int)((J * (size_t)B + kPushBlock - 1) / kPushBlock);
     HIP_TRY(hipMemsetAsync(W.qcount, 0, 16 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
     // the rays of a queue are put in key order before the scan (not the primary rays, which
@@ -1124,10 +1125,10 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     for (int depth = 0; depth < kMaxDepth; ++depth) {
         const int32_t* list = depth == 0 ? W.queue : sorted_list(kGather, depth, 0);
         hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, 0, list);
-        hipLaunchKernelGGL(k_wf_shade, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, depth);
+        hipLaunchKernelGGL(k_wf_shade, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
     }
     if (s->estimator == PT_EST_NEE) {
-        hipLaunchKernelGGL(k_wf_light, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W);
+        hipLaunchKernelGGL(k_wf_light, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
             const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi);
             hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list);
