@@ -108,6 +108,29 @@ def test_paths_match_oracle(port, name):
     r.close()
 
 
+@pytest.mark.parametrize("name", ["nee15", "bipath23", "main32", "nee15_lit"])
+def test_render_kernel_equals_path_diagnostics(name):
+    """The kernel variants that render frames (compact next-event form, records without positions for
+    path tracing) against pt_trace_paths, which runs the plain per-path form on the same samples: one
+    iteration's frame equals the per-path radiance, pixel for pixel (as numbers: the compact form may
+    give a zero the other sign)."""
+    W, H, it = 45, 19, 5
+    r = pt.Renderer(pt.preset(name, W, H, seed=17))
+    frame = r.render(it, 1).reshape(-1, 3)
+    nrows, ys, xs, rl = r.frame_layout(it)
+    idx, xy = [], []
+    for row in range(nrows):
+        for col in range(rl[row]):
+            idx.append(len(idx))
+            xy.append((xs[row, col], ys[row]))
+    n = len(idx)
+    it_idx = np.stack([np.full(n, it), np.array(idx)], axis=1).astype(np.int32)
+    g = r.trace_paths(it_idx, np.array(xy))
+    assert np.array_equal(frame[:n], g["rgb"])
+    assert np.count_nonzero(frame[n:]) == 0
+    r.close()
+
+
 def test_golden_frames(port):
     z = np.load(os.path.join(GOLDEN, "frames.npz"))
     with open(os.path.join(GOLDEN, "frames.json")) as f:
