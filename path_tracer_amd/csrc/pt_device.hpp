@@ -46,6 +46,13 @@ struct ProfScope {
     } while (0)
 #endif
 
+// ---- optional duplicate-work builds (development only: -DPT_DUP_REJECT / _SLAB / _SCREEN) -------
+// One part of the estimator is executed twice per use and the duplicate's results are kept alive
+// but discarded: paths, trip counts and images are unchanged, and the slow-down of the kernel is
+// that part's share of its time (scripts/ko_bench.sh).  Without the macros nothing is emitted.
+PTD_INLINE void keep_alive(double v) { asm volatile("" ::"v"(v)); }
+PTD_INLINE void keep_alive(int v) { asm volatile("" ::"v"(v)); }
+
 constexpr int kMaxDepth = 5;  // trace() returns at n > 4: main.cpp:368
 constexpr int kGroupBodies = 8;  // member slots per group of the grouped scan
 constexpr int kSuperGroups = 8;  // groups per super-group
@@ -592,6 +599,17 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
                                  const DScreen2* __restrict__ screen, V3 o, V3 d, int skip, double& tmin) {
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
+#ifdef PT_DUP_SLAB
+    {
+        int h2 = -1;
+        double m2 = 1.7976931348623157e308;
+        V3 dd = d;
+        asm volatile("" : "+v"(dd.x));
+        scan_all_planes<ORIGIN0, HAS_SKIP>(S, planes, o, dd, skip, h2, m2);
+        keep_alive(m2);
+        keep_alive(h2);
+    }
+#endif
     scan_all_planes<ORIGIN0, HAS_SKIP>(S, planes, o, d, skip, hit, mint);
     if (RECTS) {
         const DRect* __restrict__ rects = S.scan_rects;
@@ -610,6 +628,12 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
         }
     }
     const int n_spheres = S.n_spheres;
+#ifdef PT_DUP_SCREEN
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+    const int hit_save = hit;
+    const double mint_save = mint;
+    asm volatile("" : "+v"(d.x));
+#endif
     if (n_spheres > 0) {
         PT_PROF(kProfScanScreen);
         const RayF rf = make_rayf(ORIGIN0 ? mk(0.0, 0.0, 0.0) : o, d, S.sphere_c1max, S.sphere_r2max);
@@ -633,6 +657,15 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
             }
         }
     }
+#ifdef PT_DUP_SCREEN
+    if (rep_ == 0) {
+        keep_alive(mint);
+        keep_alive(hit);
+        hit = hit_save;
+        mint = mint_save;
+    }
+    }
+#endif
     tmin = mint;
     return hit;
 }
@@ -730,6 +763,14 @@ PTD_INLINE V3 bounce(const DMat& m, Draws& dr, V3 d, V3 n) {
         return bounce_glass(dr, d, n, m.ior, m.eta, m.refl);
     }
     PT_PROF(kProfDiffuse);
+#ifdef PT_DUP_REJECT
+    {
+        Draws cp = dr;
+        asm volatile("" : "+v"(cp.rng.s0));
+        V3 w = random_in_hemisphere(cp, n);
+        keep_alive(w.x + w.y + w.z);
+    }
+#endif
     return random_in_hemisphere(dr, n);  // Material::bounce main.cpp:250-253
 }
 

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Development only: bench the knock-out builds under scripts/ko (each leaves one part of the
-# estimator out, results are wrong on purpose) to see what that part costs in the real kernel.
+# Development only: bench the duplicate-work builds under scripts/ko (`make -C path_tracer_amd/csrc dup`:
+# each executes one part of the estimator twice and discards the duplicate, images unchanged) to see
+# what that part costs in the real kernel.   scripts/ko_bench.sh <tag> [bench args]
 set -u
 out=gpurun_out/ko_$1; shift
 mkdir -p $out
