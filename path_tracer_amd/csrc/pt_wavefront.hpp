@@ -114,6 +114,20 @@ struct TileLds {
     DScreen2 members[kTileGroups * kGroupBodies / 2];
 };
 
+// Development counters of the grouped scan (-DPT_SCAN_STATS): per wave, the screens it runs.
+#ifdef PT_SCAN_STATS
+__device__ unsigned long long g_scan_stats[8];  // waves, super pairs entered, group pairs tested, groups entered, member steps with work, evaluations, lanes-evaluating
+#define SCAN_STAT(k, v)                                                                  \
+    do {                                                                                 \
+        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) \
+            atomicAdd(&g_scan_stats[k], (unsigned long long)(v));                        \
+    } while (0)
+#else
+#define SCAN_STAT(k, v) \
+    do {                \
+    } while (0)
+#endif
+
 // The members a lane has noted for exact evaluation (slots of the grouped layout).
 struct Pending {
     uint32_t slot[4];
@@ -125,6 +139,8 @@ PTD_INLINE void pending_eval(const DScene& S, Pending& pd, V3 o, V3 d, int skip,
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
         if (__builtin_amdgcn_ballot_w64(pd.n > j) == 0) break;
+        SCAN_STAT(5, 1);
+        SCAN_STAT(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pd.n > j)));
         if (pd.n > j) {
             const int idx = order[pd.slot[j]];
             if (idx < 0) continue;  // a padding slot, reachable only by a NaN ray
@@ -155,6 +171,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     if (active) {
+        SCAN_STAT(0, 1);
         scan_all_planes<false>(S, S.scan_planes, o, d, skip, hit, mint);
         const DRect* __restrict__ rects = S.scan_rects;  // raytrace3.cpp's third shape, a short list
         const int n_rects = S.n_rects;
@@ -196,6 +213,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
                 lanemask reach[2];
                 group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->supers[sp], reach[0], reach[1]);
                 if (((reach[0] | reach[1] | long_dir)) == 0) continue;
+                SCAN_STAT(1, 1);
 #pragma unroll 1
                 for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
                     const int sside = gq / (kSuperGroups / 2);
@@ -203,10 +221,12 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
                     const int gp = sp * kSuperGroups + gq;
                     lanemask enter[2];
                     group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->bounds[gp], enter[0], enter[1]);
+                    SCAN_STAT(2, 1);
                     if (((enter[0] | enter[1] | long_dir)) == 0) continue;
 #pragma unroll 1
                     for (int side = 0; side < 2; ++side) {
                         if ((enter[side] | long_dir) == 0) continue;
+                        SCAN_STAT(3, 1);
                         const int g = 2 * gp + side;
 #pragma unroll 1
                         for (int q = 0; q < kGroupBodies / 4; ++q) {
@@ -216,6 +236,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
                             sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
                             sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
                             if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
+                            SCAN_STAT(4, 1);
 #pragma unroll
                             for (int h = 0; h < 4; ++h) {
                                 if (need[h] == 0) continue;

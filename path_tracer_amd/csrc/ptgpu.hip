@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -806,6 +807,43 @@ struct SceneUpload {
             for (int i : sph) keyed.push_back({morton(i), i});
             std::sort(keyed.begin(), keyed.end());
             for (auto& kv : keyed) order.push_back(kv.second);
+            // Within the curve's order, spatial median splits: a range is cut across the longest side
+            // of its box of centres into two parts whose sizes are multiples of a super-group (then of a
+            // group), so that every group of kGroupBodies consecutive spheres and every super-group of
+            // kSuperGroups consecutive groups is a compact cell of a kd-partition rather than a stretch
+            // of the curve, which jumps across the scene at octant borders.
+            if (!getenv("PTGPU_MORTON_GROUPS")) {
+                auto coord = [&](int i, int axis) { return axis == 0 ? geom[i].cx : axis == 1 ? geom[i].cy : geom[i].cz; };
+                struct Range { size_t a, b; };
+                std::vector<Range> todo;
+                todo.push_back({0, order.size()});
+                while (!todo.empty()) {
+                    const Range r = todo.back();
+                    todo.pop_back();
+                    const size_t cnt = r.b - r.a;
+                    if (cnt <= (size_t)kGroupBodies) continue;
+                    const size_t unit = cnt > (size_t)(kGroupBodies * kSuperGroups) ? (size_t)(kGroupBodies * kSuperGroups) : (size_t)kGroupBodies;
+                    const size_t units = (cnt + unit - 1) / unit;
+                    const size_t left = ((units + 1) / 2) * unit;  // < cnt because units >= 2
+                    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+                    for (size_t k = r.a; k < r.b; ++k)
+                        for (int ax = 0; ax < 3; ++ax) {
+                            const double v = coord(order[k], ax);
+                            if (v < blo[ax]) blo[ax] = v;
+                            if (v > bhi[ax]) bhi[ax] = v;
+                        }
+                    int axis = 0;
+                    for (int ax = 1; ax < 3; ++ax)
+                        if (bhi[ax] - blo[ax] > bhi[axis] - blo[axis]) axis = ax;
+                    std::nth_element(order.begin() + r.a, order.begin() + r.a + left, order.begin() + r.b,
+                                     [&](int x, int y) {
+                                         const double cx = coord(x, axis), cy = coord(y, axis);
+                                         return cx < cy || (cx == cy && x < y);  // NaN compares false: any order, still a permutation
+                                     });
+                    todo.push_back({r.a, r.a + left});
+                    todo.push_back({r.a + left, r.b});
+                }
+            }
             // whole pairs of super-groups (kSuperGroups groups each)
             while (order.empty() || order.size() % (2 * kSuperGroups * kGroupBodies)) order.push_back(-1);
             const int n_groups = (int)order.size() / kGroupBodies;
@@ -1769,6 +1807,18 @@ int pt_brdf_lookup_vectors(pt_scene* s, int id, const double* vec6, int n, doubl
 }
 
 }  // extern "C"
+
+#ifdef PT_SCAN_STATS
+// Development only: counters of the grouped scan since the last call (and reset).
+extern "C" int pt_scan_stats(unsigned long long* out) {
+    unsigned long long h[8] = {};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ptw::g_scan_stats), sizeof h) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out[k] = h[k];
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ptw::g_scan_stats), z, sizeof z) != hipSuccess) return -1;
+    return 8;
+}
+#endif
 
 #ifdef PT_PROFILE_SECTIONS
 // Development only: cycles per section summed over waves since the last call (and reset).
