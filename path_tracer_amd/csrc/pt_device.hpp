@@ -233,6 +233,7 @@ struct DScene {
     // (n_groups is even); bounds and members are float (centre, r^2) records, two per DScreen2;
     // grp_order[slot] is the body index of a member slot (-1: padding).
     const DScreen2* grp_supers;  // bounds of kSuperGroups consecutive groups (n_groups is a multiple of 2 kSuperGroups)
+    const DScreen2* grp_halves;  // per tile of the LDS-tiled scan: the bounds of its two halves
     const DScreen2* grp_bounds;
     const DScreen2* grp_members;
     const int32_t* grp_order;

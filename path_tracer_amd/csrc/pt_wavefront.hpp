@@ -209,7 +209,12 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
         }
         __syncthreads();
         if (active) {
+            // the two halves of the tile first (a scalar load: the record is the same for the whole wave)
+            lanemask half[2];
+            group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, S.grp_halves[base / kTileGroups], half[0], half[1]);
+            constexpr int kHalfPairs = kTileGroups / kSuperGroups / 4;  // super-group pairs per half
             for (int sp = 0; sp < cnt / kSuperGroups / 2; ++sp) {
+                if ((half[sp / kHalfPairs] | long_dir) == 0) continue;
                 lanemask reach[2];
                 group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->supers[sp], reach[0], reach[1]);
                 if (((reach[0] | reach[1] | long_dir)) == 0) continue;

@@ -494,7 +494,7 @@ struct pt_scene {
     Partition part;
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
-    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_order;
+    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_halves, d_grp_order;
     DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins, d_scan_rects, d_scan_rects_mt;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
@@ -822,7 +822,8 @@ struct SceneUpload {
                     todo.pop_back();
                     const size_t cnt = r.b - r.a;
                     if (cnt <= (size_t)kGroupBodies) continue;
-                    const size_t unit = cnt > (size_t)(kGroupBodies * kSuperGroups) ? (size_t)(kGroupBodies * kSuperGroups) : (size_t)kGroupBodies;
+                    const size_t half_tile = (size_t)ptw::kTileGroups * kGroupBodies / 2, super = (size_t)kGroupBodies * kSuperGroups;
+                    const size_t unit = cnt > half_tile ? half_tile : cnt > super ? super : (size_t)kGroupBodies;
                     const size_t units = (cnt + unit - 1) / unit;
                     const size_t left = ((units + 1) / 2) * unit;  // < cnt because units >= 2
                     double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
@@ -892,19 +893,19 @@ struct SceneUpload {
                 r.cz[g & 1] = fc[2];
                 r.r2[g & 1] = fr2;
             }
-            // second level: a bounding sphere around the bounds of kSuperGroups consecutive groups
-            const int n_super = n_groups / kSuperGroups;
-            std::vector<DScreen2> supers(n_super / 2);
-            for (int sg = 0; sg < n_super; ++sg) {
+            // Bounding sphere (float centre, radius rounded outwards) of the spheres in member slots
+            // [first, first + count), measured from the spheres themselves around the centre actually
+            // stored; nothing there: radius -inf (parked below).
+            auto bound_of_slots = [&](size_t first, size_t count, DScreen2& r, int side) {
                 double c[3] = {0.0, 0.0, 0.0};
                 int cnt = 0;
-                for (int k = 0; k < kSuperGroups; ++k) {
-                    const int g = sg * kSuperGroups + k;
-                    const DScreen2& b = bounds[g / 2];
-                    if (!(b.r2[g & 1] >= 0.0f)) continue;  // empty group
-                    c[0] += b.cx[g & 1];
-                    c[1] += b.cy[g & 1];
-                    c[2] += b.cz[g & 1];
+                const size_t last = std::min(order.size(), first + count);
+                for (size_t k = first; k < last; ++k) {
+                    const int i = order[k];
+                    if (i < 0) continue;
+                    c[0] += geom[i].cx;
+                    c[1] += geom[i].cy;
+                    c[2] += geom[i].cz;
                     cnt++;
                 }
                 float fc[3] = {0.0f, 0.0f, 0.0f};
@@ -912,24 +913,33 @@ struct SceneUpload {
                 if (cnt > 0) {
                     for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
                     double R = 0.0;
-                    for (int k = 0; k < kSuperGroups; ++k) {
-                        const int g = sg * kSuperGroups + k;
-                        const DScreen2& b = bounds[g / 2];
-                        if (!(b.r2[g & 1] >= 0.0f)) continue;
-                        const double dx = (double)b.cx[g & 1] - fc[0], dy = (double)b.cy[g & 1] - fc[1], dz = (double)b.cz[g & 1] - fc[2];
-                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)b.r2[g & 1]);  // r2 holds the group's R
+                    for (size_t k = first; k < last; ++k) {
+                        const int i = order[k];
+                        if (i < 0) continue;
+                        const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
+                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
                     }
-                    fr2 = std::nextafter((float)(R * (1.0 + 2e-6)), INFINITY);
-                    if (!(fr2 >= 0.0f)) fr2 = INFINITY;
+                    fr2 = std::nextafter((float)(R * (1.0 + 2e-6)), INFINITY);  // the record keeps R, see group_possible2_masks
+                    if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
                     c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
                     if (std::isfinite(fr2)) r2max = std::max(r2max, fr2 * fr2 * 1.00001f);
                 }
-                DScreen2& r = supers[sg / 2];
-                r.cx[sg & 1] = fc[0];
-                r.cy[sg & 1] = fc[1];
-                r.cz[sg & 1] = fc[2];
-                r.r2[sg & 1] = fr2;
-            }
+                r.cx[side] = fc[0];
+                r.cy[side] = fc[1];
+                r.cz[side] = fc[2];
+                r.r2[side] = fr2;
+            };
+            // second level: kSuperGroups consecutive groups; third level: the two halves of a tile of
+            // kTileGroups groups (what a block stages through LDS at a time)
+            const int n_super = n_groups / kSuperGroups;
+            std::vector<DScreen2> supers(n_super / 2);
+            for (int sg = 0; sg < n_super; ++sg)
+                bound_of_slots((size_t)sg * kSuperGroups * kGroupBodies, (size_t)kSuperGroups * kGroupBodies, supers[sg / 2], sg & 1);
+            const size_t tile_slots = (size_t)ptw::kTileGroups * kGroupBodies;
+            const int n_tiles = (int)((order.size() + tile_slots - 1) / tile_slots);
+            std::vector<DScreen2> halves((size_t)n_tiles);
+            for (int t = 0; t < n_tiles; ++t)
+                for (int h = 0; h < 2; ++h) bound_of_slots((size_t)t * tile_slots + (size_t)h * (tile_slots / 2), tile_slots / 2, halves[t], h);
             // An empty group or super-group (radius -inf above) must never be entered.  With the record
             // holding R, not R^2, that is said by a centre far outside any scene and R = 0: for
             // |d| <= 1 the discriminant is about -|D|^2 (1 - cos^2) - ... <= -2e36, far below every error
@@ -945,10 +955,14 @@ struct SceneUpload {
             };
             park_empty(bounds);
             park_empty(supers);
+            park_empty(halves);
             int rcg;
             if ((rcg = s->d_grp_supers.ensure(sizeof(DScreen2) * supers.size()))) return rcg;
             HIP_TRY(hipMemcpy(s->d_grp_supers.p, supers.data(), sizeof(DScreen2) * supers.size(), hipMemcpyHostToDevice));
             D.grp_supers = (const DScreen2*)s->d_grp_supers.p;
+            if ((rcg = s->d_grp_halves.ensure(sizeof(DScreen2) * halves.size()))) return rcg;
+            HIP_TRY(hipMemcpy(s->d_grp_halves.p, halves.data(), sizeof(DScreen2) * halves.size(), hipMemcpyHostToDevice));
+            D.grp_halves = (const DScreen2*)s->d_grp_halves.p;
             if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
             if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
             if ((rcg = s->d_grp_order.ensure(sizeof(int32_t) * order.size()))) return rcg;
@@ -1282,6 +1296,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_grp_members.release();
     s->d_grp_bounds.release();
     s->d_grp_supers.release();
+    s->d_grp_halves.release();
     s->d_grp_order.release();
     s->d_scan_planes.release();
     s->d_scan_spheres.release();
