@@ -860,39 +860,6 @@ struct SceneUpload {
                 r.cz[k & 1] = sphere ? geom[i].fcz : other;
                 r.r2[k & 1] = sphere ? geom[i].fr2 : (i >= 0 ? std::nanf("") : -INFINITY);
             }
-            for (int g = 0; g < n_groups; ++g) {
-                DScreen2& r = bounds[g / 2];
-                double c[3] = {0.0, 0.0, 0.0};
-                int cnt = 0;
-                for (int k = 0; k < kGroupBodies; ++k) {
-                    const int i = order[(size_t)g * kGroupBodies + k];
-                    if (i < 0) continue;
-                    c[0] += geom[i].cx;
-                    c[1] += geom[i].cy;
-                    c[2] += geom[i].cz;
-                    cnt++;
-                }
-                float fc[3] = {0.0f, 0.0f, 0.0f};
-                float fr2 = -INFINITY;  // empty group: never entered
-                if (cnt > 0) {
-                    for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
-                    double R = 0.0;  // measured from the float centre actually stored
-                    for (int k = 0; k < kGroupBodies; ++k) {
-                        const int i = order[(size_t)g * kGroupBodies + k];
-                        if (i < 0) continue;
-                        const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
-                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
-                    }
-                    fr2 = std::nextafter((float)(R * (1.0 + 2e-6)), INFINITY);  // the record keeps R, see group_possible2_masks
-                    if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
-                    c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
-                    if (std::isfinite(fr2)) r2max = std::max(r2max, fr2 * fr2 * 1.00001f);
-                }
-                r.cx[g & 1] = fc[0];
-                r.cy[g & 1] = fc[1];
-                r.cz[g & 1] = fc[2];
-                r.r2[g & 1] = fr2;
-            }
             // Bounding sphere (float centre, radius rounded outwards) of the spheres in member slots
             // [first, first + count), measured from the spheres themselves around the centre actually
             // stored; nothing there: radius -inf (parked below).
@@ -911,7 +878,30 @@ struct SceneUpload {
                 float fc[3] = {0.0f, 0.0f, 0.0f};
                 float fr2 = -INFINITY;
                 if (cnt > 0) {
-                    for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
+                    // centre: from the centroid towards the smallest enclosing ball (Badoiu-Clarkson steps
+                    // towards the farthest sphere); any centre is valid, a better one gives a smaller radius
+                    double ctr[3] = {c[0] / cnt, c[1] / cnt, c[2] / cnt};
+                    for (int it = 1; it <= 64 && cnt > 1; ++it) {
+                        double far = -1.0, fv[3] = {0.0, 0.0, 0.0};
+                        for (size_t k = first; k < last; ++k) {
+                            const int i = order[k];
+                            if (i < 0) continue;
+                            const double dx = geom[i].cx - ctr[0], dy = geom[i].cy - ctr[1], dz = geom[i].cz - ctr[2];
+                            const double dist = std::sqrt(dx * dx + dy * dy + dz * dz), reach = dist + std::sqrt(geom[i].nx);
+                            if (reach > far && dist > 0.0) {
+                                far = reach;
+                                const double pull = reach / dist;  // towards the far side of that sphere
+                                fv[0] = dx * pull;
+                                fv[1] = dy * pull;
+                                fv[2] = dz * pull;
+                            }
+                        }
+                        if (!(far > 0.0) || !std::isfinite(far)) break;
+                        for (int k = 0; k < 3; ++k) ctr[k] += fv[k] / (it + 1.0);
+                    }
+                    for (int k = 0; k < 3; ++k) fc[k] = (float)ctr[k];
+                    if (!std::isfinite(fc[0]) || !std::isfinite(fc[1]) || !std::isfinite(fc[2]))
+                        for (int k = 0; k < 3; ++k) fc[k] = (float)(c[k] / cnt);
                     double R = 0.0;
                     for (size_t k = first; k < last; ++k) {
                         const int i = order[k];
@@ -929,6 +919,7 @@ struct SceneUpload {
                 r.cz[side] = fc[2];
                 r.r2[side] = fr2;
             };
+            for (int g = 0; g < n_groups; ++g) bound_of_slots((size_t)g * kGroupBodies, (size_t)kGroupBodies, bounds[g / 2], g & 1);
             // second level: kSuperGroups consecutive groups; third level: the two halves of a tile of
             // kTileGroups groups (what a block stages through LDS at a time)
             const int n_super = n_groups / kSuperGroups;
