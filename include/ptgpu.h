@@ -156,7 +156,8 @@ int pt_tiles_unpack(pt_scene* scene, int world, int tiles_per_rank, const double
 /* Two device pipelines compute the same estimator with identical results.  FUSED: one kernel per
  * batch, path state in registers/LDS, body list read through the scalar cache (up to 127 bodies).
  * WAVEFRONT: one kernel per stage over compacted queues of live paths, path state in HBM, body
- * list staged through LDS in tiles (any body count).  AUTO picks FUSED when it applies.
+ * list as a bounding hierarchy read through the scalar cache (any body count).  AUTO picks FUSED
+ * when it applies.
  * No counterpart in the reference (its trace() is one recursive function, main.cpp:367-405). */
 enum { PT_PIPELINE_AUTO = 0, PT_PIPELINE_FUSED = 1, PT_PIPELINE_WAVEFRONT = 2 };
 int pt_set_pipeline(pt_scene* scene, int pipeline);

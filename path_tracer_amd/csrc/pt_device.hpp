@@ -218,7 +218,7 @@ struct DMat {  // 96 bytes
     int32_t pad[3];
 };
 
-// Screening records of the LDS-tiled scan: sphere centre and radius^2 in float, two consecutive
+// Screening records of the grouped scan: sphere centre and radius^2 in float, two consecutive
 // bodies interleaved per 32-byte record so that a pair is screened with packed FP32 instructions
 // (v_pk_add/mul/fma_f32).  For every non-sphere (and the padding slot of an odd body count) r2 is
 // NaN, which makes the screen inconclusive so that the full record is examined.
@@ -229,11 +229,11 @@ struct DScreen2 {
 
 struct DScene {
     const DGeom* geom;
-    // Grouped layout of the LDS-tiled scan: n_groups groups of kGroupBodies member slots
+    // Grouped layout of the large-scene scan: n_groups groups of kGroupBodies member slots
     // (n_groups is even); bounds and members are float (centre, r^2) records, two per DScreen2;
     // grp_order[slot] is the body index of a member slot (-1: padding).
     const DScreen2* grp_supers;  // bounds of kSuperGroups consecutive groups (n_groups is a multiple of 2 kSuperGroups)
-    const DScreen2* grp_halves;  // per tile of the LDS-tiled scan: the bounds of its two halves
+    const DScreen2* grp_halves;  // per section of kSectionGroups groups: the bounds of its two halves
     const DScreen2* grp_bounds;
     const DScreen2* grp_members;
     const int32_t* grp_order;

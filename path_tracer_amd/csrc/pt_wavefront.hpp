@@ -1,6 +1,6 @@
 // Wavefront form of the estimator for scenes too large for the fused kernel: path state lives in
 // HBM (structure of arrays), each stage is its own kernel over a compacted queue of live paths,
-// and the nearest-hit scan stages the body list through LDS in tiles.
+// and the nearest-hit scan walks a bounding hierarchy of the spheres with scalar loads.
 //
 //   k_wf_generate        camera rays, per-path RNG streams, queue 0
 //   k_wf_extend<GATHER>  nearest hit of the current ray           (main.cpp:372-383)
@@ -92,27 +92,24 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 }
 
 // Nearest-hit scan of large scenes.  Planes are scanned first, exactly as in the fused kernel.
-// The spheres are arranged in spatially compact groups of kGroupBodies (built at upload, along a
-// Morton curve).  The float screening records of a tile of groups (group bounds and member
-// spheres, 16 B each) are staged once per block through LDS.  Per pair of groups a wave runs the
-// packed bounding-sphere screen (broadcast LDS reads), first on super-groups of kSuperGroups
-// groups, then on the groups of those it might reach; only the groups some lane's ray might enter
-// have their members screened, four per step; a lane whose screen of a member is inconclusive
-// notes the member's slot in a four-entry list of its own, and whenever some lane's list is full
-// every lane evaluates its noted members in FP64 from the full records (per-lane loads).  So the
-// FP64 work is per lane, not per wave: a wave of 64 unrelated rays meets some 200 members, a lane
-// three or four.  The bound screen is valid for |d| <= 1 — a hit by the reference's formula
-// b < 0, b^2 > |D|^2 - r^2 then implies |o - c_B|_Q < R in the norm |v|_Q^2 = |v|^2 - (v.d)^2, and
-// an origin outside the bound has the bound's centre ahead — so lanes with a longer direction
-// examine every group.  Results are merged with the explicit rule
+// The spheres are arranged in spatially compact groups of kGroupBodies (built at upload by median
+// splits), kSuperGroups groups to a super-group, kSectionGroups groups to a section whose two
+// halves have bounds of their own.  Every level's float screening records (16 B per bound or
+// member, two to a record) are the same for all lanes of a wave, so they are read with scalar
+// loads straight from global memory (the whole structure is some 18 B per sphere and stays in L2):
+// no staging, no barriers, waves progress independently.  Per pair of bounds a wave runs the
+// packed bounding-sphere screen, first on the two halves of a section, then on the super-groups
+// of a half some lane might reach, then on their groups; only the groups some lane's ray might
+// enter have their members screened, four per step; a lane whose screen of a member is
+// inconclusive notes the member's slot in a four-entry list of its own, and whenever some lane's
+// list is full every lane evaluates its noted members in FP64 from the full records (per-lane
+// loads).  So the FP64 work is per lane, not per wave: a wave of 64 unrelated rays meets some 200
+// members, a lane three or four.  The bound screen is valid for |d| <= 1 — a hit by the
+// reference's formula b < 0, b^2 > |D|^2 - r^2 then implies |o - c_B|_Q < R in the norm
+// |v|_Q^2 = |v|^2 - (v.d)^2, and an origin outside the bound has the bound's centre ahead — so
+// lanes with a longer direction examine every group.  Results are merged with the explicit rule
 // (t < mint) || (t == mint && index > hit), which makes them independent of the order.
-// Every thread of the block must call it (barriers inside); `active` masks threads without a ray.
-constexpr int kTileGroups = 1024 / kGroupBodies;  // bounds + 1024 members, 16 B each: <= 18 KiB of LDS per block
-struct TileLds {
-    DScreen2 supers[kTileGroups / kSuperGroups / 2];
-    DScreen2 bounds[kTileGroups / 2];
-    DScreen2 members[kTileGroups * kGroupBodies / 2];
-};
+constexpr int kSectionGroups = 1024 / kGroupBodies;
 
 // Development counters of the grouped scan (-DPT_SCAN_STATS): per wave, the screens it runs.
 #ifdef PT_SCAN_STATS
@@ -158,7 +155,9 @@ PTD_INLINE void pending_eval(const DScene& S, Pending& pd, V3 o, V3 d, int skip,
     pd.n = 0;
 }
 
-PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool active, TileLds* tile, double& tmin) {
+// Called by whole waves with a ray in every participating lane (idle lanes of a partial wave do
+// not enter).
+PTD_INLINE int nearest_hit_grouped(const DScene& S, V3 o, V3 d, int skip, double& tmin) {
     const RayF rf = make_rayf(o, d, S.sphere_c1max, S.sphere_r2max);
     const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
     const float e_disc = rf.e_disc, e_b = rf.e_b;
@@ -170,91 +169,79 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
     auto cut_of = [&](double m) { return two_len * ((float)m * 1.00001f); };
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
-    if (active) {
-        SCAN_STAT(0, 1);
-        scan_all_planes<false>(S, S.scan_planes, o, d, skip, hit, mint);
-        const DRect* __restrict__ rects = S.scan_rects;  // raytrace3.cpp's third shape, a short list
-        const int n_rects = S.n_rects;
-        for (int k = 0; k < n_rects; ++k) {
-            double t;
-            const bool ok = scan_rect(rects[k], o, d, t);
-            merge_hit(ok, t, rects[k].body, skip, S.hit_eps, hit, mint);
-        }
-        const DRectMT* __restrict__ rects_mt = S.scan_rects_mt;  // light_tracing.cpp's rectangle, likewise
-        const int n_rects_mt = S.n_rects_mt;
-        for (int k = 0; k < n_rects_mt; ++k) {
-            double t;
-            const bool ok = scan_rect_mt(rects_mt[k], o, d, S.mt_eps, t);
-            merge_hit(ok, t, rects_mt[k].body, skip, S.hit_eps, hit, mint);
-        }
+    SCAN_STAT(0, 1);
+    scan_all_planes<false>(S, S.scan_planes, o, d, skip, hit, mint);
+    const DRect* __restrict__ rects = S.scan_rects;  // raytrace3.cpp's third shape, a short list
+    const int n_rects = S.n_rects;
+    for (int k = 0; k < n_rects; ++k) {
+        double t;
+        const bool ok = scan_rect(rects[k], o, d, t);
+        merge_hit(ok, t, rects[k].body, skip, S.hit_eps, hit, mint);
+    }
+    const DRectMT* __restrict__ rects_mt = S.scan_rects_mt;  // light_tracing.cpp's rectangle, likewise
+    const int n_rects_mt = S.n_rects_mt;
+    for (int k = 0; k < n_rects_mt; ++k) {
+        double t;
+        const bool ok = scan_rect_mt(rects_mt[k], o, d, S.mt_eps, t);
+        merge_hit(ok, t, rects_mt[k].body, skip, S.hit_eps, hit, mint);
     }
     Pending pd;
     pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
     pd.n = 0u;
     float tau = cut_of(mint);  // DBL_MAX converts to +inf: no cut before the first hit
-    const int n_groups = S.n_groups;
-    for (int base = 0; base < n_groups; base += kTileGroups) {
-        const int cnt = min(kTileGroups, n_groups - base);  // a multiple of 2 kSuperGroups
-        __syncthreads();  // the previous tile has been consumed by every wave
-        {
-            const uint4* ssrc = reinterpret_cast<const uint4*>(S.grp_supers + base / kSuperGroups / 2);
-            uint4* sdst = reinterpret_cast<uint4*>(tile->supers);
-            for (int k = threadIdx.x; k < cnt / kSuperGroups; k += blockDim.x) sdst[k] = ssrc[k];
-            const uint4* bsrc = reinterpret_cast<const uint4*>(S.grp_bounds + base / 2);
-            uint4* bdst = reinterpret_cast<uint4*>(tile->bounds);
-            for (int k = threadIdx.x; k < cnt; k += blockDim.x) bdst[k] = bsrc[k];  // 16 B per lane, coalesced
-            const uint4* msrc = reinterpret_cast<const uint4*>(S.grp_members + (size_t)base * kGroupBodies / 2);
-            uint4* mdst = reinterpret_cast<uint4*>(tile->members);
-            for (int k = threadIdx.x; k < cnt * kGroupBodies; k += blockDim.x) mdst[k] = msrc[k];
-        }
-        __syncthreads();
-        if (active) {
-            // the two halves of the tile first (a scalar load: the record is the same for the whole wave)
-            lanemask half[2];
-            group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, S.grp_halves[base / kTileGroups], half[0], half[1]);
-            constexpr int kHalfPairs = kTileGroups / kSuperGroups / 4;  // super-group pairs per half
-            for (int sp = 0; sp < cnt / kSuperGroups / 2; ++sp) {
-                if ((half[sp / kHalfPairs] | long_dir) == 0) continue;
-                lanemask reach[2];
-                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->supers[sp], reach[0], reach[1]);
-                if (((reach[0] | reach[1] | long_dir)) == 0) continue;
-                SCAN_STAT(1, 1);
+    const DScreen2* __restrict__ halves = S.grp_halves;
+    const DScreen2* __restrict__ supers = S.grp_supers;
+    const DScreen2* __restrict__ bounds = S.grp_bounds;
+    const DScreen2* __restrict__ members = S.grp_members;
+    const int n_groups = S.n_groups;  // a multiple of 2 kSuperGroups
+    constexpr int kHalfPairs = kSectionGroups / kSuperGroups / 4;  // super-group pairs per half
+    for (int base = 0; base < n_groups; base += kSectionGroups) {
+        const int n_pairs = min(kSectionGroups, n_groups - base) / kSuperGroups / 2;
+        lanemask half[2];
+        group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, halves[base / kSectionGroups], half[0], half[1]);
+        if ((half[0] | half[1] | long_dir) == 0) continue;
+        for (int sp = 0; sp < n_pairs; ++sp) {
+            if ((half[sp / kHalfPairs] | long_dir) == 0) continue;
+            const int spg = base / kSuperGroups / 2 + sp;  // super-group pair of the scene
+            lanemask reach[2];
+            group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, supers[spg], reach[0], reach[1]);
+            if (((reach[0] | reach[1] | long_dir)) == 0) continue;
+            SCAN_STAT(1, 1);
 #pragma unroll 1
-                for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
-                    const int sside = gq / (kSuperGroups / 2);
-                    if ((reach[sside] | long_dir) == 0) continue;
-                    const int gp = sp * kSuperGroups + gq;
-                    lanemask enter[2];
-                    group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, tile->bounds[gp], enter[0], enter[1]);
-                    SCAN_STAT(2, 1);
-                    if (((enter[0] | enter[1] | long_dir)) == 0) continue;
+            for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
+                const int sside = gq / (kSuperGroups / 2);
+                if ((reach[sside] | long_dir) == 0) continue;
+                const int gp = spg * kSuperGroups + gq;  // group pair of the scene
+                lanemask enter[2];
+                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, bounds[gp], enter[0], enter[1]);
+                SCAN_STAT(2, 1);
+                if (((enter[0] | enter[1] | long_dir)) == 0) continue;
 #pragma unroll 1
-                    for (int side = 0; side < 2; ++side) {
-                        if ((enter[side] | long_dir) == 0) continue;
-                        SCAN_STAT(3, 1);
-                        const int g = 2 * gp + side;
+                for (int side = 0; side < 2; ++side) {
+                    if ((enter[side] | long_dir) == 0) continue;
+                    SCAN_STAT(3, 1);
+                    const int g = 2 * gp + side;
 #pragma unroll 1
-                        for (int q = 0; q < kGroupBodies / 4; ++q) {
-                            const DScreen2 sa = tile->members[g * (kGroupBodies / 2) + 2 * q];  // LDS broadcast
-                            const DScreen2 sb = tile->members[g * (kGroupBodies / 2) + 2 * q + 1];
-                            lanemask need[4];
-                            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
-                            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
-                            if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
-                            SCAN_STAT(4, 1);
+                    for (int q = 0; q < kGroupBodies / 4; ++q) {
+                        const DScreen2 sa = members[(size_t)g * (kGroupBodies / 2) + 2 * q];
+                        const DScreen2 sb = members[(size_t)g * (kGroupBodies / 2) + 2 * q + 1];
+                        lanemask need[4];
+                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
+                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
+                        if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
+                        SCAN_STAT(4, 1);
 #pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                if (need[h] == 0) continue;
-                                const uint32_t slot = (uint32_t)((base + g) * kGroupBodies + 4 * q + h);
-                                // the lanes of need[h] append `slot` to their lists
+                        for (int h = 0; h < 4; ++h) {
+                            if (need[h] == 0) continue;
+                            const uint32_t slot = (uint32_t)(g * kGroupBodies + 4 * q + h);
+                            // the lanes of need[h] append `slot` to their lists
 #pragma unroll
-                                for (uint32_t j = 0; j < 4; ++j)
-                                    pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
-                                pd.n += sel32(need[h], 1u, 0u);
-                                if (PTD_MASK(pd.n == 4u) != 0) {
-                                    pending_eval(S, pd, o, d, skip, hit, mint);
-                                    tau = cut_of(mint);
-                                }
+                            for (uint32_t j = 0; j < 4; ++j)
+                                pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
+                            pd.n += sel32(need[h], 1u, 0u);
+                            if (PTD_MASK(pd.n == 4u) != 0) {
+                                pending_eval(S, pd, o, d, skip, hit, mint);
+                                tau = cut_of(mint);
                             }
                         }
                     }
@@ -262,7 +249,7 @@ PTD_INLINE int nearest_hit_tiled(const DScene& S, V3 o, V3 d, int skip, bool act
             }
         }
     }
-    if (active) pending_eval(S, pd, o, d, skip, hit, mint);
+    pending_eval(S, pd, o, d, skip, hit, mint);
     tmin = mint;
     return hit;
 }
@@ -406,26 +393,22 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_ray_keys(DScene S, WfState W, i
 }
 
 // One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.
+// One wave to a block: nothing is shared between waves, and a block of one ends as soon as its
+// own rays are done.
+constexpr int kExtBlock = 64;
 template <int MODE>
-__global__ void __launch_bounds__(kWfBlock) k_wf_extend(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ list) {
-    __shared__ TileLds s_tile;
+__global__ void __launch_bounds__(kExtBlock) k_wf_extend(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ list) {
     const int count = W.qcount[qi];
-    const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if ((int)(blockIdx.x * kWfBlock) >= count) return;  // whole block idle
-    const bool active = i < count;
-    size_t p = 0;
-    V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 1.0);
-    int skip = -1;
-    if (active) {
-        p = (size_t)list[i];  // queue qi, possibly reordered
-        queue_ray<MODE>(S, W, p, gi, o, d, skip);
-    }
+    const int i = blockIdx.x * kExtBlock + threadIdx.x;
+    if (i >= count) return;
+    const size_t p = (size_t)list[i];  // queue qi, possibly reordered
+    V3 o, d;
+    int skip;
+    queue_ray<MODE>(S, W, p, gi, o, d, skip);
     double mint;
-    int hit = nearest_hit_tiled(S, o, d, skip, active, &s_tile, mint);
-    if (active) {
-        W.hit[p] = hit;
-        W.t[p] = mint;
-    }
+    const int hit = nearest_hit_grouped(S, o, d, skip, mint);
+    W.hit[p] = hit;
+    W.t[p] = mint;
 }
 
 // Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.

@@ -573,7 +573,7 @@ int ensure_render_buffers(pt_scene* s) {
 constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
 
 // Builds and uploads everything the kernels read about a scene: body and material records, the
-// compact scan lists with their slabs, the grouped layout of the tiled scan, the rectangle list, the
+// compact scan lists with their slabs, the grouped layout of the large-scene scan, the rectangle list, the
 // scene-wide flags.  One step per method, in the order of run().
 struct SceneUpload {
     pt_scene* s;
@@ -768,7 +768,7 @@ struct SceneUpload {
         }
     }
 
-    // Grouped layout of the LDS-tiled scan (wavefront pipeline): the spheres in groups of
+    // Grouped layout of the large-scene scan (wavefront pipeline): the spheres in groups of
     // kGroupBodies, ordered along a Morton curve so that a group is spatially compact.  Per group a
     // bounding sphere in float (centre, R^2 rounded outwards): a wave examines the members only when
     // some lane's ray might enter the bound.  Member records are the float (centre, r^2) pairs of
@@ -822,8 +822,8 @@ struct SceneUpload {
                     todo.pop_back();
                     const size_t cnt = r.b - r.a;
                     if (cnt <= (size_t)kGroupBodies) continue;
-                    const size_t half_tile = (size_t)ptw::kTileGroups * kGroupBodies / 2, super = (size_t)kGroupBodies * kSuperGroups;
-                    const size_t unit = cnt > half_tile ? half_tile : cnt > super ? super : (size_t)kGroupBodies;
+                    const size_t half_section = (size_t)ptw::kSectionGroups * kGroupBodies / 2, super = (size_t)kGroupBodies * kSuperGroups;
+                    const size_t unit = cnt > half_section ? half_section : cnt > super ? super : (size_t)kGroupBodies;
                     const size_t units = (cnt + unit - 1) / unit;
                     const size_t left = ((units + 1) / 2) * unit;  // < cnt because units >= 2
                     double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
@@ -920,17 +920,17 @@ struct SceneUpload {
                 r.r2[side] = fr2;
             };
             for (int g = 0; g < n_groups; ++g) bound_of_slots((size_t)g * kGroupBodies, (size_t)kGroupBodies, bounds[g / 2], g & 1);
-            // second level: kSuperGroups consecutive groups; third level: the two halves of a tile of
-            // kTileGroups groups (what a block stages through LDS at a time)
+            // second level: kSuperGroups consecutive groups; third level: the two halves of a section of
+            // kSectionGroups groups
             const int n_super = n_groups / kSuperGroups;
             std::vector<DScreen2> supers(n_super / 2);
             for (int sg = 0; sg < n_super; ++sg)
                 bound_of_slots((size_t)sg * kSuperGroups * kGroupBodies, (size_t)kSuperGroups * kGroupBodies, supers[sg / 2], sg & 1);
-            const size_t tile_slots = (size_t)ptw::kTileGroups * kGroupBodies;
-            const int n_tiles = (int)((order.size() + tile_slots - 1) / tile_slots);
-            std::vector<DScreen2> halves((size_t)n_tiles);
-            for (int t = 0; t < n_tiles; ++t)
-                for (int h = 0; h < 2; ++h) bound_of_slots((size_t)t * tile_slots + (size_t)h * (tile_slots / 2), tile_slots / 2, halves[t], h);
+            const size_t section_slots = (size_t)ptw::kSectionGroups * kGroupBodies;
+            const int n_sections = (int)((order.size() + section_slots - 1) / section_slots);
+            std::vector<DScreen2> halves((size_t)n_sections);
+            for (int t = 0; t < n_sections; ++t)
+                for (int h = 0; h < 2; ++h) bound_of_slots((size_t)t * section_slots + (size_t)h * (section_slots / 2), section_slots / 2, halves[t], h);
             // An empty group or super-group (radius -inf above) must never be entered.  With the record
             // holding R, not R^2, that is said by a centre far outside any scene and R = 0: for
             // |d| <= 1 the discriminant is about -|D|^2 (1 - cos^2) - ... <= -2e36, far below every error
@@ -1147,6 +1147,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const Partition P = s->part;
     const int nblk = (int)((J * (size_t)B + kWfBlock - 1) / kWfBlock);
     const int nblk_push = (int)((J * (size_t)B + kPushBlock - 1) / kPushBlock);
+    const int nblk_ext = (int)((J * (size_t)B + kExtBlock - 1) / kExtBlock);
     HIP_TRY(hipMemsetAsync(W.qcount, 0, 16 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
     // the rays of a queue are put in key order before the scan (not the primary rays, which
@@ -1167,14 +1168,14 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     };
     for (int depth = 0; depth < kMaxDepth; ++depth) {
         const int32_t* list = depth == 0 ? W.queue : sorted_list(kGather, depth, 0);
-        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, depth, 0, list);
+        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list);
         hipLaunchKernelGGL(k_wf_shade, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
     }
     if (s->estimator == PT_EST_NEE) {
         hipLaunchKernelGGL(k_wf_light, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
             const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi);
-            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list);
+            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list);
             if (s->has_measured)
                 hipLaunchKernelGGL((k_wf_nee<true, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
             else

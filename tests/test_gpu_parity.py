@@ -392,7 +392,7 @@ def test_open_scene_paths_terminate(port, name):
     r.close()
 
 
-def test_large_scene_uses_lds_tiled_scan(port):
+def test_large_scene_uses_grouped_scan(port):
     # 1000 and 10000 bodies: beyond the fused kernel's limit, the wavefront pipeline is selected
     for name, W, H, n_it in (("synthetic1k", 24, 16, 2), ("synthetic10k", 10, 6, 1)):
         r = pt.Renderer(pt.preset(name, W, H, seed=9))
@@ -413,7 +413,7 @@ def test_large_scene_uses_lds_tiled_scan(port):
 
 def test_ten_thousand_bodies_across_many_blocks(port):
     """The 10 000-body scene at a size where every stage of the wavefront pipeline spans many blocks
-    (64x48x2 = 6144 paths, 24 blocks of 256): ray sorting, queue compaction and the tiled scan
+    (64x48x2 = 6144 paths, 24 blocks of 256): ray sorting, queue compaction and the grouped scan
     against the oracle, bit for bit (about ten seconds of CPU)."""
     W, H, n_it = 64, 48, 2
     r = pt.Renderer(pt.preset("synthetic10k", W, H, seed=4))
