@@ -227,16 +227,24 @@ struct DScreen2 {
     f32x2 cx, cy, cz, r2;  // .x: body 2k, .y: body 2k+1
 };
 
+// The exact record of a member slot of the grouped scan: what Sphere::intersect needs, and the
+// body's index (-1: a padding slot), side by side so that one round trip fetches both.
+struct DSlotExact {  // 48 bytes
+    double cx, cy, cz, r2;
+    int32_t body;
+    int32_t pad[3];
+};
+
 struct DScene {
     const DGeom* geom;
     // Grouped layout of the large-scene scan: n_groups groups of kGroupBodies member slots
     // (n_groups is even); bounds and members are float (centre, r^2) records, two per DScreen2;
-    // grp_order[slot] is the body index of a member slot (-1: padding).
+    // grp_exact[slot] is the FP64 record of a member slot.
     const DScreen2* grp_supers;  // bounds of kSuperGroups consecutive groups (n_groups is a multiple of 2 kSuperGroups)
     const DScreen2* grp_halves;  // per section of kSectionGroups groups: the bounds of its two halves
     const DScreen2* grp_bounds;
     const DScreen2* grp_members;
-    const int32_t* grp_order;
+    const DSlotExact* grp_exact;
     int32_t n_groups;
     float sort_mid[3], sort_inv[3];  // origin cells of the ray sort: cell coordinate = (o - mid) * inv in [-1, 1]
     // Compact lists of the fused scan (body index in pad[0]): the planes that belong to no slab;
@@ -897,11 +905,17 @@ PTD_INLINE void vector_to_spherical(V3 in, double& theta, double& phi) {
 // outwards): a member can only be hit when the ray starts inside the bound (c < 0) or meets it ahead
 // (disc >= 0 and b < 0); evaluated in float with the error bounds of make_rayf (e_disc also bounds the
 // error of c and of |D|^2).  R = +inf always passes, -inf never.
-// Distance cut: a sphere inside the bound that the reference's formula hits from outside has
-// t = C / (beta + sqrt(beta^2 - C)) >= C / (2 beta) with C = |D|^2 - r^2 >= delta |D| and
-// beta = -D.d <= |D| |d|, delta = |o - c_B| - R the distance from the origin to the bound: so
-// t >= delta / (2 |d|).  A lane whose nearest hit so far is mint cannot improve on it inside a bound
-// with delta > tau = 2 |d| mint (tau is passed rounded up; +inf disables the cut).
+// Distance cut: a sphere (c, r) that the reference's formula hits from outside, D = o - c, A = |D|,
+// has t = C / (beta + sqrt(beta^2 - C)) with C = A^2 - r^2 and beta = -D.d <= s A, s = |d|; t falls
+// as beta grows, and at beta = s A the inequality t >= (A - r) / s reduces to
+// A^2 (1 - s^2) >= r^2 (1 - s^2): true for s <= 1.  A sphere inside the bound has
+// A - r >= delta = |o - c_B| - R, so t >= delta / s, and a lane whose nearest hit so far is mint cannot
+// improve on it (nor tie with it) inside a bound with delta > s mint.  That is for the formula in
+// exact arithmetic; evaluated in FP64 its t is lower by at most sqrt(2e-15 (A^2 + r^2)) < 7e-8 (A + r)
+// (the square root of the rounding error of the discriminant, reached at grazing incidence), which is
+// what the margins are for: the stored R is 2.5e-4 too large and tau is passed as 1.0004 s mint (+inf
+// disables the cut), so a bound is cut only when delta - s mint > 2e-4 (R + s mint), far above the
+// error wherever the cut can apply (A + r < 2 (R + s mint) + delta).
 PTD_INLINE void group_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
                                       float e_b, float tau, const DScreen2& sc, lanemask& m0, lanemask& m1) {
     f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;

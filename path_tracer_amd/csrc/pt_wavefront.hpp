@@ -130,26 +130,38 @@ struct Pending {
     uint32_t slot[4];
     uint32_t n;
 };
+#ifndef PT_EVAL_BATCH
+#define PT_EVAL_BATCH 2
+#endif
+// The records of PT_EVAL_BATCH noted members are requested before the first is used.
 PTD_INLINE void pending_eval(const DScene& S, Pending& pd, V3 o, V3 d, int skip, int& hit, double& mint) {
-    const DGeom* __restrict__ geom = S.geom;
-    const int32_t* __restrict__ order = S.grp_order;
+    const DSlotExact* __restrict__ exact = S.grp_exact;
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-        if (__builtin_amdgcn_ballot_w64(pd.n > j) == 0) break;
-        SCAN_STAT(5, 1);
-        SCAN_STAT(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pd.n > j)));
-        if (pd.n > j) {
-            const int idx = order[pd.slot[j]];
-            if (idx < 0) continue;  // a padding slot, reachable only by a NaN ray
-            const DGeom* g = geom + idx;
-            DGeom s;
-            s.cx = g->cx;
-            s.cy = g->cy;
-            s.cz = g->cz;
-            s.nx = g->nx;
-            double t;
-            const bool ok = scan_sphere_exact(s, o, d, t);
-            merge_hit(ok, t, idx, skip, S.hit_eps, hit, mint);
+    for (uint32_t j0 = 0; j0 < 4; j0 += PT_EVAL_BATCH) {
+        if (__builtin_amdgcn_ballot_w64(pd.n > j0) == 0) break;
+        DGeom s[PT_EVAL_BATCH];
+        int body[PT_EVAL_BATCH];
+#pragma unroll
+        for (uint32_t k = 0; k < PT_EVAL_BATCH; ++k) {
+            body[k] = -1;
+            if (pd.n > j0 + k) {
+                const DSlotExact* e = exact + pd.slot[j0 + k];
+                s[k].cx = e->cx;
+                s[k].cy = e->cy;
+                s[k].cz = e->cz;
+                s[k].nx = e->r2;
+                body[k] = e->body;  // -1: a padding slot, reachable only by a NaN ray
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PT_EVAL_BATCH; ++k) {
+            if (k > 0 && __builtin_amdgcn_ballot_w64(pd.n > j0 + k) == 0) break;
+            SCAN_STAT(5, 1);
+            if (body[k] >= 0) {
+                double t;
+                const bool ok = scan_sphere_exact(s[k], o, d, t);
+                merge_hit(ok, t, body[k], skip, S.hit_eps, hit, mint);
+            }
         }
     }
     pd.n = 0;
@@ -163,10 +175,11 @@ PTD_INLINE int nearest_hit_grouped(const DScene& S, V3 o, V3 d, int skip, double
     const float e_disc = rf.e_disc, e_b = rf.e_b;
     const float dlen2 = fdx * fdx + fdy * fdy + fdz * fdz;
     const lanemask long_dir = PTD_MASK(!(dlen2 <= 1.000001f));
-    // tau = 2 |d| mint of the distance cut (group_possible2_masks), rounded up; lanes outside the
-    // screen's validity (|d| > 1, NaN) never cut
-    const float two_len = (dlen2 <= 1.000001f) ? 2.0f * __builtin_sqrtf(dlen2) * 1.00001f : INFINITY;
-    auto cut_of = [&](double m) { return two_len * ((float)m * 1.00001f); };
+    // tau = |d| mint of the distance cut (group_possible2_masks) with its margin; the cut's proof needs
+    // |d| <= 1 of the FP64 direction itself, and lanes outside the screen's validity (|d| > 1, NaN) never cut
+    const bool short_dir = (d.x * d.x + d.y * d.y + d.z * d.z) <= 1.0 + 1e-12;
+    const float cut_len = (short_dir && dlen2 <= 1.000001f) ? __builtin_sqrtf(dlen2) * 1.0004f : INFINITY;
+    auto cut_of = [&](double m) { return cut_len * ((float)m * 1.00001f); };
     int hit = -1;
     double mint = 1.7976931348623157e308;  // DBL_MAX
     SCAN_STAT(0, 1);

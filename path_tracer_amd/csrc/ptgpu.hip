@@ -494,7 +494,7 @@ struct pt_scene {
     Partition part;
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
-    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_halves, d_grp_order;
+    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_halves, d_grp_exact;
     DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins, d_scan_rects, d_scan_rects_mt;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
@@ -772,8 +772,8 @@ struct SceneUpload {
     // kGroupBodies, ordered along a Morton curve so that a group is spatially compact.  Per group a
     // bounding sphere in float (centre, R^2 rounded outwards): a wave examines the members only when
     // some lane's ray might enter the bound.  Member records are the float (centre, r^2) pairs of
-    // the per-body screen; slots past the end can never pass (r^2 = -inf).  grp_order maps member
-    // slots to body indices.  (Planes are scanned from the plane list, as in the fused kernel.)
+    // the per-body screen; slots past the end can never pass (r^2 = -inf).  grp_exact holds, per member
+    // slot, the FP64 record and the body index.  (Planes are scanned from the plane list, as in the fused kernel.)
     int sphere_groups() {
         std::vector<int32_t> order;
         {
@@ -909,7 +909,8 @@ struct SceneUpload {
                         const double dx = geom[i].cx - fc[0], dy = geom[i].cy - fc[1], dz = geom[i].cz - fc[2];
                         R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(geom[i].nx));
                     }
-                    fr2 = std::nextafter((float)(R * (1.0 + 2e-6)), INFINITY);  // the record keeps R, see group_possible2_masks
+                    // the record keeps R, enlarged by the 2.5e-4 the distance cut of group_possible2_masks asks for
+                    fr2 = std::nextafter((float)(R * (1.0 + 2.5e-4)), INFINITY);
                     if (!(fr2 >= 0.0f)) fr2 = INFINITY;  // NaN: always enter
                     c1max = std::max(c1max, std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]));
                     if (std::isfinite(fr2)) r2max = std::max(r2max, fr2 * fr2 * 1.00001f);
@@ -956,13 +957,26 @@ struct SceneUpload {
             D.grp_halves = (const DScreen2*)s->d_grp_halves.p;
             if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
             if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
-            if ((rcg = s->d_grp_order.ensure(sizeof(int32_t) * order.size()))) return rcg;
+            std::vector<DSlotExact> exact(order.size());
+            for (size_t k = 0; k < order.size(); ++k) {
+                DSlotExact& e = exact[k];
+                memset(&e, 0, sizeof e);
+                e.body = order[k];
+                if (order[k] >= 0) {
+                    const DGeom& g = geom[order[k]];
+                    e.cx = g.cx;
+                    e.cy = g.cy;
+                    e.cz = g.cz;
+                    e.r2 = g.nx;
+                }
+            }
+            if ((rcg = s->d_grp_exact.ensure(sizeof(DSlotExact) * exact.size()))) return rcg;
             HIP_TRY(hipMemcpy(s->d_grp_members.p, members.data(), sizeof(DScreen2) * members.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(s->d_grp_bounds.p, bounds.data(), sizeof(DScreen2) * bounds.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(s->d_grp_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s->d_grp_exact.p, exact.data(), sizeof(DSlotExact) * exact.size(), hipMemcpyHostToDevice));
             D.grp_members = (const DScreen2*)s->d_grp_members.p;
             D.grp_bounds = (const DScreen2*)s->d_grp_bounds.p;
-            D.grp_order = (const int32_t*)s->d_grp_order.p;
+            D.grp_exact = (const DSlotExact*)s->d_grp_exact.p;
             D.n_groups = n_groups;
             for (int k = 0; k < 3; ++k) {  // box of the sphere centres (the whole scene when there are none)
                 const bool any = hi[k] > lo[k];
@@ -1289,7 +1303,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_grp_bounds.release();
     s->d_grp_supers.release();
     s->d_grp_halves.release();
-    s->d_grp_order.release();
+    s->d_grp_exact.release();
     s->d_scan_planes.release();
     s->d_scan_spheres.release();
     s->d_scan_screen.release();
