@@ -47,9 +47,10 @@ struct WfState {
 // LDS).  Atomics on one counter retire at about one per 9 ns, which is what a push costs: the
 // shading stages therefore run blocks of kPushBlock threads, a quarter of the atomics of 256-thread
 // blocks.  Every thread of the block must call it; `slots` is blockDim.x / 64 + 1 words of LDS.  The
-// order of a queue is arbitrary; no result depends on it.
+// order of a queue is arbitrary; no result depends on it.  Returns the position of the thread's entry
+// (-1 without one).
 constexpr int kPushBlock = 1024;
-PTD_INLINE void queue_push(int32_t* q, int32_t* count, bool pred, int value, int32_t* slots) {
+PTD_INLINE int queue_push(int32_t* q, int32_t* count, bool pred, int value, int32_t* slots) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (int)(blockDim.x >> 6);
     __syncthreads();  // `slots` may still be read from the previous push
@@ -65,7 +66,9 @@ PTD_INLINE void queue_push(int32_t* q, int32_t* count, bool pred, int value, int
         slots[nwaves] = total ? atomicAdd(count, total) : 0;
     }
     __syncthreads();
-    if (pred) q[slots[nwaves] + slots[wave] + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = value;
+    const int pos = slots[nwaves] + slots[wave] + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (pred) q[pos] = value;
+    return pred ? pos : -1;
 }
 
 PTD_INLINE Rng load_rng(const WfState& W, size_t p) {
@@ -424,19 +427,24 @@ __global__ void __launch_bounds__(kExtBlock) k_wf_extend(DScene S, WfState W, in
     W.t[p] = mint;
 }
 
-// Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.
+// Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.  KEYS: the sort key of
+// a survivor's new ray is stored at its queue position (W.keys was filled with the end key), which
+// spares the next scan's sort a pass over the rays.
+template <bool KEYS>
 __global__ void __launch_bounds__(kPushBlock) k_wf_shade(DScene S, WfState W, int qi, int depth) {
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kPushBlock + threadIdx.x;
     if ((int)(blockIdx.x * kPushBlock) >= count) return;
     bool alive = false;
     size_t p = 0;
+    V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 0.0);
     if (i < count) {
         p = (size_t)W.queue[(size_t)qi * W.cap + i];
         const int hit = W.hit[p];
         if (hit >= 0) {
             alive = true;
-            V3 o = load3(W.ray, W.cap, p, 0), d = load3(W.ray, W.cap, p, 3);
+            o = load3(W.ray, W.cap, p, 0);
+            d = load3(W.ray, W.cap, p, 3);
             Draws dr;
             dr.rng = load_rng(W, p);
             dr.count = 0;
@@ -454,7 +462,8 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_shade(DScene S, WfState W, in
         }
     }
     __shared__ int32_t s_push[kPushBlock / 64 + 1];
-    queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
+    const int pos = queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
+    if (KEYS && alive) W.keys[pos] = ray_key<kGather>(S, o, d);
 }
 
 constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks of vertex 0

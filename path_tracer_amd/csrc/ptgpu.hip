@@ -1166,12 +1166,11 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
     // the rays of a queue are put in key order before the scan (not the primary rays, which
     // leave k_wf_generate in pixel order)
+    // (the keys of a gather queue were written by the shading stage that filled it)
+    const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
     auto sorted_list = [&](int mode, int qi, int gi) -> const int32_t* {
         if (!s->wf_sort) return W.queue + (size_t)qi * W.cap;
-        const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
-        if (mode == kGather)
-            hipLaunchKernelGGL((k_wf_ray_keys<kGather>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi, cap);
-        else
+        if (mode == kShadow)
             hipLaunchKernelGGL((k_wf_ray_keys<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi, cap);
         uint32_t* keys_out = (uint32_t*)s->d_wf_sort.p;
         void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
@@ -1183,7 +1182,12 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     for (int depth = 0; depth < kMaxDepth; ++depth) {
         const int32_t* list = depth == 0 ? W.queue : sorted_list(kGather, depth, 0);
         hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list);
-        hipLaunchKernelGGL(k_wf_shade, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
+        if (s->wf_sort && depth + 1 < kMaxDepth) {  // the next queue will be sorted: end keys everywhere, then the survivors' keys
+            HIP_TRY(hipMemsetAsync(W.keys, 0xFF, (size_t)cap * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_wf_shade<true>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
+        } else {
+            hipLaunchKernelGGL(k_wf_shade<false>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
+        }
     }
     if (s->estimator == PT_EST_NEE) {
         hipLaunchKernelGGL(k_wf_light, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
