@@ -242,6 +242,11 @@ struct DScene {
     // grp_exact[slot] is the FP64 record of a member slot.
     const DScreen2* grp_supers;  // bounds of kSuperGroups consecutive groups (n_groups is a multiple of 2 kSuperGroups)
     const DScreen2* grp_halves;  // per section of kSectionGroups groups: the bounds of its two halves
+    const float* grp_half4;      // the same bounds one by one: (cx, cy, cz, R) of half h at [4 h]
+    // Visiting order of the halves, nearest first, for rays starting in each of the kOrderCells^3 cells
+    // of the sort box: entry [cell * 32 + k] packs the halves of step k as h0 | h1 << 8.  Null when the
+    // scene has more than 64 halves (they are then visited in index order).
+    const uint32_t* grp_half_order;
     const DScreen2* grp_bounds;
     const DScreen2* grp_members;
     const DSlotExact* grp_exact;

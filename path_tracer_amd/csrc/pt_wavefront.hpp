@@ -94,6 +94,12 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
     a[(size_t)(first + 2) * cap + p] = v.z;
 }
 
+PTD_INLINE uint32_t grid_cell(float u, int cells) {  // u in [-1, 1] -> 0..cells-1, NaN -> 0
+    int c = (int)((u + 1.0f) * (0.5f * (float)cells));
+    c = c < cells - 1 ? c : cells - 1;
+    return (uint32_t)(c > 0 ? c : 0);
+}
+
 // Nearest-hit scan of large scenes.  Planes are scanned first, exactly as in the fused kernel.
 // The spheres are arranged in spatially compact groups of kGroupBodies (built at upload by median
 // splits), kSuperGroups groups to a super-group, kSectionGroups groups to a section whose two
@@ -101,8 +107,8 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 // member, two to a record) are the same for all lanes of a wave, so they are read with scalar
 // loads straight from global memory (the whole structure is some 18 B per sphere and stays in L2):
 // no staging, no barriers, waves progress independently.  Per pair of bounds a wave runs the
-// packed bounding-sphere screen, first on the two halves of a section, then on the super-groups
-// of a half some lane might reach, then on their groups; only the groups some lane's ray might
+// packed bounding-sphere screen, first on the halves of the sections (nearest first, from a table
+// per origin cell), then on the super-groups of a half some lane might reach, then on their groups; only the groups some lane's ray might
 // enter have their members screened, four per step; a lane whose screen of a member is
 // inconclusive notes the member's slot in a four-entry list of its own, and whenever some lane's
 // list is full every lane evaluates its noted members in FP64 from the full records (per-lane
@@ -113,6 +119,7 @@ PTD_INLINE void store3(double* a, size_t cap, size_t p, int first, V3 v) {
 // lanes with a longer direction examine every group.  Results are merged with the explicit rule
 // (t < mint) || (t == mint && index > hit), which makes them independent of the order.
 constexpr int kSectionGroups = 1024 / kGroupBodies;
+constexpr int kOrderCells = 8;  // cells per axis of the visiting-order table (DScene::grp_half_order)
 
 // Development counters of the grouped scan (-DPT_SCAN_STATS): per wave, the screens it runs.
 #ifdef PT_SCAN_STATS
@@ -205,59 +212,89 @@ PTD_INLINE int nearest_hit_grouped(const DScene& S, V3 o, V3 d, int skip, double
     pd.slot[0] = pd.slot[1] = pd.slot[2] = pd.slot[3] = 0u;
     pd.n = 0u;
     float tau = cut_of(mint);  // DBL_MAX converts to +inf: no cut before the first hit
-    const DScreen2* __restrict__ halves = S.grp_halves;
+    const float* __restrict__ half4 = S.grp_half4;
     const DScreen2* __restrict__ supers = S.grp_supers;
     const DScreen2* __restrict__ bounds = S.grp_bounds;
     const DScreen2* __restrict__ members = S.grp_members;
     const int n_groups = S.n_groups;  // a multiple of 2 kSuperGroups
     constexpr int kHalfPairs = kSectionGroups / kSuperGroups / 4;  // super-group pairs per half
-    for (int base = 0; base < n_groups; base += kSectionGroups) {
-        const int n_pairs = min(kSectionGroups, n_groups - base) / kSuperGroups / 2;
+    const int n_super_pairs = n_groups / kSuperGroups / 2;
+    const int n_halves = 2 * ((n_groups + kSectionGroups - 1) / kSectionGroups);
+    // The halves are visited nearest first (by the cell the wave's first ray starts in): once a near
+    // hit is known the distance cut disposes of the far ones at this level.  Any order gives the same
+    // result.
+    const uint32_t* __restrict__ order = S.grp_half_order;
+    if (order) {
+        const uint32_t cx = grid_cell((fox - S.sort_mid[0]) * S.sort_inv[0], kOrderCells);
+        const uint32_t cy = grid_cell((foy - S.sort_mid[1]) * S.sort_inv[1], kOrderCells);
+        const uint32_t cz = grid_cell((foz - S.sort_mid[2]) * S.sort_inv[2], kOrderCells);
+        order += (size_t)__builtin_amdgcn_readfirstlane((int)((cz * kOrderCells + cy) * kOrderCells + cx)) * 32;
+    }
+#pragma unroll 1
+    for (int k = 0; k < n_halves; k += 2) {
+        int h2[2] = {k, k + 1};
+        if (order) {
+            const uint32_t pk = order[k / 2];
+            h2[0] = (int)(pk & 0xffu);
+            h2[1] = (int)(pk >> 8);
+        }
+        const float4 ra = *reinterpret_cast<const float4*>(half4 + 4 * h2[0]);
+        const float4 rb = *reinterpret_cast<const float4*>(half4 + 4 * h2[1]);
+        DScreen2 hrec;
+        hrec.cx = f32x2{ra.x, rb.x};
+        hrec.cy = f32x2{ra.y, rb.y};
+        hrec.cz = f32x2{ra.z, rb.z};
+        hrec.r2 = f32x2{ra.w, rb.w};
         lanemask half[2];
-        group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, halves[base / kSectionGroups], half[0], half[1]);
+        group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, hrec, half[0], half[1]);
         if ((half[0] | half[1] | long_dir) == 0) continue;
-        for (int sp = 0; sp < n_pairs; ++sp) {
-            if ((half[sp / kHalfPairs] | long_dir) == 0) continue;
-            const int spg = base / kSuperGroups / 2 + sp;  // super-group pair of the scene
-            lanemask reach[2];
-            group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, supers[spg], reach[0], reach[1]);
-            if (((reach[0] | reach[1] | long_dir)) == 0) continue;
-            SCAN_STAT(1, 1);
 #pragma unroll 1
-            for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
-                const int sside = gq / (kSuperGroups / 2);
-                if ((reach[sside] | long_dir) == 0) continue;
-                const int gp = spg * kSuperGroups + gq;  // group pair of the scene
-                lanemask enter[2];
-                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, bounds[gp], enter[0], enter[1]);
-                SCAN_STAT(2, 1);
-                if (((enter[0] | enter[1] | long_dir)) == 0) continue;
+        for (int w = 0; w < 2; ++w) {
+            if ((half[w] | long_dir) == 0) continue;
+            const int spg0 = h2[w] * kHalfPairs;  // first super-group pair of the half
+            const int n_pairs = min(kHalfPairs, n_super_pairs - spg0);  // <= 0: the scene ends before this half
+            for (int sp = 0; sp < n_pairs; ++sp) {
+                const int spg = spg0 + sp;  // super-group pair of the scene
+                lanemask reach[2];
+                group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, supers[spg], reach[0], reach[1]);
+                if (((reach[0] | reach[1] | long_dir)) == 0) continue;
+                SCAN_STAT(1, 1);
 #pragma unroll 1
-                for (int side = 0; side < 2; ++side) {
-                    if ((enter[side] | long_dir) == 0) continue;
-                    SCAN_STAT(3, 1);
-                    const int g = 2 * gp + side;
+                for (int gq = 0; gq < kSuperGroups; ++gq) {  // the 2 x kSuperGroups groups of the pair, two at a time
+                    const int sside = gq / (kSuperGroups / 2);
+                    if ((reach[sside] | long_dir) == 0) continue;
+                    const int gp = spg * kSuperGroups + gq;  // group pair of the scene
+                    lanemask enter[2];
+                    group_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, tau, bounds[gp], enter[0], enter[1]);
+                    SCAN_STAT(2, 1);
+                    if (((enter[0] | enter[1] | long_dir)) == 0) continue;
 #pragma unroll 1
-                    for (int q = 0; q < kGroupBodies / 4; ++q) {
-                        const DScreen2 sa = members[(size_t)g * (kGroupBodies / 2) + 2 * q];
-                        const DScreen2 sb = members[(size_t)g * (kGroupBodies / 2) + 2 * q + 1];
-                        lanemask need[4];
-                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
-                        sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
-                        if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
-                        SCAN_STAT(4, 1);
+                    for (int side = 0; side < 2; ++side) {
+                        if ((enter[side] | long_dir) == 0) continue;
+                        SCAN_STAT(3, 1);
+                        const int g = 2 * gp + side;
+#pragma unroll 1
+                        for (int q = 0; q < kGroupBodies / 4; ++q) {
+                            const DScreen2 sa = members[(size_t)g * (kGroupBodies / 2) + 2 * q];
+                            const DScreen2 sb = members[(size_t)g * (kGroupBodies / 2) + 2 * q + 1];
+                            lanemask need[4];
+                            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sa, need[0], need[1]);
+                            sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sb, need[2], need[3]);
+                            if ((need[0] | need[1] | need[2] | need[3]) == 0) continue;
+                            SCAN_STAT(4, 1);
 #pragma unroll
-                        for (int h = 0; h < 4; ++h) {
-                            if (need[h] == 0) continue;
-                            const uint32_t slot = (uint32_t)(g * kGroupBodies + 4 * q + h);
-                            // the lanes of need[h] append `slot` to their lists
+                            for (int h = 0; h < 4; ++h) {
+                                if (need[h] == 0) continue;
+                                const uint32_t slot = (uint32_t)(g * kGroupBodies + 4 * q + h);
+                                // the lanes of need[h] append `slot` to their lists
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j)
-                                pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
-                            pd.n += sel32(need[h], 1u, 0u);
-                            if (PTD_MASK(pd.n == 4u) != 0) {
-                                pending_eval(S, pd, o, d, skip, hit, mint);
-                                tau = cut_of(mint);
+                                for (uint32_t j = 0; j < 4; ++j)
+                                    pd.slot[j] = sel32(need[h] & PTD_MASK(pd.n == j), slot, pd.slot[j]);
+                                pd.n += sel32(need[h], 1u, 0u);
+                                if (PTD_MASK(pd.n == 4u) != 0) {
+                                    pending_eval(S, pd, o, d, skip, hit, mint);
+                                    tau = cut_of(mint);
+                                }
                             }
                         }
                     }
@@ -341,11 +378,6 @@ PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V
 // 3x3 / 10^3 2.72e8, 2x2 / 12^3 2.68e8, faces only / 16^3 2.54e8 paths/s.)  One radix sort of the
 // 16-bit keys per scan (rocprim, path ids as values; stable, so a bin keeps the queue's order).  The
 // order of a queue is invisible in the results.
-PTD_INLINE uint32_t grid_cell(float u, int cells) {  // u in [-1, 1] -> 0..cells-1, NaN -> 0
-    int c = (int)((u + 1.0f) * (0.5f * (float)cells));
-    c = c < cells - 1 ? c : cells - 1;
-    return (uint32_t)(c > 0 ? c : 0);
-}
 #ifndef PT_KEY_D
 #define PT_KEY_D 4
 #endif

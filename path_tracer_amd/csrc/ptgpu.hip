@@ -494,7 +494,7 @@ struct pt_scene {
     Partition part;
     DScene ds;
     DevBuf d_geom, d_mat, d_lights, d_brdf[PT_MAX_BRDF];
-    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_halves, d_grp_exact;
+    DevBuf d_grp_members, d_grp_bounds, d_grp_supers, d_grp_halves, d_grp_half4, d_grp_half_order, d_grp_exact;
     DevBuf d_scan_planes, d_scan_spheres, d_scan_screen, d_scan_screen0, d_brdf_bins, d_scan_rects, d_scan_rects_mt;
     // frame tables and samples are double-buffered: the layout of batch k+1 and the accumulation of
     // batch k-1 overlap the estimator kernel of batch k on two side streams
@@ -955,6 +955,45 @@ struct SceneUpload {
             if ((rcg = s->d_grp_halves.ensure(sizeof(DScreen2) * halves.size()))) return rcg;
             HIP_TRY(hipMemcpy(s->d_grp_halves.p, halves.data(), sizeof(DScreen2) * halves.size(), hipMemcpyHostToDevice));
             D.grp_halves = (const DScreen2*)s->d_grp_halves.p;
+            const size_t n_halves = 2 * halves.size();
+            std::vector<float> half4(4 * n_halves);
+            for (size_t h = 0; h < n_halves; ++h) {
+                const DScreen2& r = halves[h / 2];
+                half4[4 * h + 0] = r.cx[h & 1];
+                half4[4 * h + 1] = r.cy[h & 1];
+                half4[4 * h + 2] = r.cz[h & 1];
+                half4[4 * h + 3] = r.r2[h & 1];
+            }
+            if ((rcg = s->d_grp_half4.ensure(sizeof(float) * half4.size()))) return rcg;
+            HIP_TRY(hipMemcpy(s->d_grp_half4.p, half4.data(), sizeof(float) * half4.size(), hipMemcpyHostToDevice));
+            D.grp_half4 = (const float*)s->d_grp_half4.p;
+            D.grp_half_order = nullptr;
+            if (n_halves <= 64 && !getenv("PTGPU_INDEX_ORDER")) {  // (the variable: index order, for tests of that path)
+                // per cell of the sort box (see ray_key) the halves by distance from the cell's centre
+                const int C = ptw::kOrderCells;
+                std::vector<uint32_t> table((size_t)C * C * C * 32, 0u);
+                std::vector<std::pair<float, int>> byd(n_halves);
+                for (int cz = 0; cz < C; ++cz)
+                    for (int cy = 0; cy < C; ++cy)
+                        for (int cx = 0; cx < C; ++cx) {
+                            const int cc[3] = {cx, cy, cz};
+                            float p[3];
+                            for (int k = 0; k < 3; ++k) {
+                                const bool any = hi[k] > lo[k];
+                                p[k] = any ? (float)(lo[k] + (cc[k] + 0.5) * (hi[k] - lo[k]) / C) : 0.0f;
+                            }
+                            for (size_t h = 0; h < n_halves; ++h) {
+                                const float dx = p[0] - half4[4 * h], dy = p[1] - half4[4 * h + 1], dz = p[2] - half4[4 * h + 2];
+                                byd[h] = {std::sqrt(dx * dx + dy * dy + dz * dz) - half4[4 * h + 3], (int)h};
+                            }
+                            std::sort(byd.begin(), byd.end());
+                            uint32_t* row = table.data() + ((size_t)(cz * C + cy) * C + cx) * 32;
+                            for (size_t k = 0; k < n_halves; k += 2) row[k / 2] = (uint32_t)byd[k].second | ((uint32_t)byd[k + 1].second << 8);
+                        }
+                if ((rcg = s->d_grp_half_order.ensure(sizeof(uint32_t) * table.size()))) return rcg;
+                HIP_TRY(hipMemcpy(s->d_grp_half_order.p, table.data(), sizeof(uint32_t) * table.size(), hipMemcpyHostToDevice));
+                D.grp_half_order = (const uint32_t*)s->d_grp_half_order.p;
+            }
             if ((rcg = s->d_grp_members.ensure(sizeof(DScreen2) * members.size()))) return rcg;
             if ((rcg = s->d_grp_bounds.ensure(sizeof(DScreen2) * bounds.size()))) return rcg;
             std::vector<DSlotExact> exact(order.size());
@@ -1307,6 +1346,8 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_grp_bounds.release();
     s->d_grp_supers.release();
     s->d_grp_halves.release();
+    s->d_grp_half4.release();
+    s->d_grp_half_order.release();
     s->d_grp_exact.release();
     s->d_scan_planes.release();
     s->d_scan_spheres.release();

@@ -425,6 +425,25 @@ def test_ten_thousand_bodies_across_many_blocks(port):
     r.close()
 
 
+def test_visiting_order_of_the_scan_is_invisible(monkeypatch):
+    """The grouped scan visits the top of its hierarchy nearest first from a table built at upload;
+    scenes too large for the table are visited in index order.  PTGPU_INDEX_ORDER selects that path
+    for any scene: same frame and same nearest hits, bit for bit."""
+    W, H, n_it = 48, 32, 2
+    rng = np.random.default_rng(11)
+    rays = np.concatenate([np.stack([rng.uniform(-1.8, 1.8, 800), rng.uniform(-2.4, 4.4, 800), rng.uniform(-0.45, 2.4, 800)], axis=1),
+                           rng.normal(size=(800, 3))], axis=1)
+    out = []
+    for index_order in (False, True):
+        if index_order:
+            monkeypatch.setenv("PTGPU_INDEX_ORDER", "1")
+        r = pt.Renderer(pt.preset("synthetic10k", W, H, seed=6))
+        out.append((r.render(0, n_it),) + tuple(r.intersect_batch(rays)))
+        r.close()
+    assert same_bits(out[0][0], out[1][0]) and np.count_nonzero(out[0][0]) > 0.3 * out[0][0].size
+    assert np.array_equal(out[0][1], out[1][1]) and same_bits(out[0][2], out[1][2])
+
+
 def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
     """`next_event W H iters threads` and `main ...`: PPM bytes equal save() of the oracle's buffer, with
     the reference's worker arithmetic (iters/threads frames per worker, divide by the requested total)."""
