@@ -24,22 +24,95 @@ using namespace ptd;
 
 constexpr int kWfBlock = 256;
 
+// The scans visit the paths in ray-key order, i.e. at scattered path ids: what a scan reads and
+// writes per path is kept together so that it costs one cache line, not one per component (as
+// structure-of-arrays columns the gather scans fetched 600 B per ray from HBM).
+struct alignas(64) RayRec {  // the path's current ray and the result of its scan
+    double ox, oy, oz, dx, dy, dz;
+    double t;     // distance of the last scan
+    int32_t hit;  // body of the last scan
+    int32_t pad;
+};
+struct alignas(32) VertexRec {  // a recorded vertex: the offset point and its body
+    double x, y, z;
+    int32_t body;
+    int32_t shadow;  // the path's light (set by k_wf_light) until the vertex's shadow scan stores the body it hit
+};
+
+// A wave that owns one record per lane at arbitrary path ids moves the records four lanes to a
+// record (two for the vertex records), 16 bytes a lane: every load or store instruction then covers
+// whole records instead of a sixteen-byte piece of 64 different ones, which is what the memory
+// pipeline is built for (the per-lane form made the shading stage twice as slow).  The records pass
+// through `tile`, 64 x 64 bytes of LDS owned by the wave.  Every lane of the wave must call; lanes
+// with on == false move nothing (and get zeros).
+constexpr uint32_t kNoPath = 0xffffffffu;
+PTD_INLINE uint32_t wave_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+PTD_INLINE RayRec wave_load_rays(const RayRec* __restrict__ rays, uint32_t p, bool on, uint4* tile) {
+    const uint32_t lane = wave_lane(), piece = lane & 3u;
+    const uint32_t mine = on ? p : kNoPath;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t ps = (uint32_t)__shfl((int)mine, (int)(r * 16u + (lane >> 2)));
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (ps != kNoPath) v = reinterpret_cast<const uint4*>(rays + ps)[piece];
+        tile[r * 64u + lane] = v;  // piece `piece` of the record of lane r * 16 + lane / 4
+    }
+    __builtin_amdgcn_wave_barrier();
+    RayRec out;
+    uint4* o4 = reinterpret_cast<uint4*>(&out);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) o4[k] = tile[lane * 4u + k];
+    __builtin_amdgcn_wave_barrier();
+    return out;
+}
+// PIECES: how many 16-byte pieces of each record are written (3: origin and direction only).
+template <int PIECES = 4>
+PTD_INLINE void wave_store_rays(RayRec* __restrict__ rays, uint32_t p, bool on, const RayRec& rec, uint4* tile) {
+    const uint32_t lane = wave_lane(), piece = lane & 3u;
+    const uint32_t mine = on ? p : kNoPath;
+    const uint4* i4 = reinterpret_cast<const uint4*>(&rec);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) tile[lane * 4u + k] = i4[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t ps = (uint32_t)__shfl((int)mine, (int)(r * 16u + (lane >> 2)));
+        const uint4 v = tile[r * 64u + lane];
+        if (ps != kNoPath && (int)piece < PIECES) reinterpret_cast<uint4*>(rays + ps)[piece] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// Vertex records: element `index` of `verts` per lane, two lanes to a record.
+PTD_INLINE void wave_store_verts(VertexRec* __restrict__ verts, uint32_t index, bool on, const VertexRec& rec, uint4* tile) {
+    const uint32_t lane = wave_lane(), piece = lane & 1u;
+    const uint32_t mine = on ? index : kNoPath;
+    const uint4* i4 = reinterpret_cast<const uint4*>(&rec);
+    tile[lane * 2u] = i4[0];
+    tile[lane * 2u + 1u] = i4[1];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t r = 0; r < 2; ++r) {
+        const uint32_t is = (uint32_t)__shfl((int)mine, (int)(r * 32u + (lane >> 1)));
+        const uint4 v = tile[r * 64u + lane];
+        if (is != kNoPath) reinterpret_cast<uint4*>(verts + is)[piece] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct WfState {
-    double* ray;     // [6][cap]  origin xyz, direction xyz
+    RayRec* rays;      // [cap]
+    VertexRec* verts;  // [kMaxDepth][cap]
     double* xy;      // [2][cap]  image-plane coordinates of the sample
-    double* pts;     // [15][cap] recorded offset points, (vertex*3 + component)
     double* L;       // [3][cap]  running colour
-    double* t;       // [cap]     distance of the last scan
     uint32_t* rng;   // [4][cap]
-    int32_t* hit;    // [cap]     body of the last scan
-    int32_t* bod;    // [5][cap]  recorded bodies
     int32_t* nrec;   // [cap]
     int32_t* light;  // [cap]
     int32_t* need;   // [cap]     1 + deepest emitting vertex (scenes with a dead direct term), else 0
     int32_t* queue;  // [11][cap] 0..5: paths with more than d-1 records; 6..10: shadow tasks of vertex 0..4
     int32_t* qcount; // [16]
-    int32_t* sorted; // [cap]     a queue reordered by ray key (see k_wf_ray_keys)
-    uint32_t* keys;  // [cap]
+    int32_t* sorted; // [cap]     a queue reordered by ray key (see ray_key)
+    uint32_t* keys;  // [cap]     sort keys of the next gather queue, by queue position
+    uint32_t* skeys; // [5][cap]  sort keys of the shadow-task queues
     size_t cap;
 };
 
@@ -321,6 +394,9 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
     const int slot = slot_of_fn(P, blockIdx.x, tid, Wd, H);
     const size_t p = (size_t)b * J + (size_t)blockIdx.x * kWfBlock + tid;
     const bool valid = slot >= 0 && slot < npix[b];
+    RayRec rr;
+    rr.ox = rr.oy = rr.oz = rr.dx = rr.dy = rr.dz = rr.t = 0.0;
+    rr.hit = -1, rr.pad = 0;
     if (valid) {
         const int32_t* rs = row_start + (size_t)b * (H + 1);
         int r = slot / Wd;
@@ -337,8 +413,7 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         double y = ys[(size_t)b * H + r];
         V3 o = ld3(S.cam_o);
         V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157
-        store3(W.ray, W.cap, p, 0, o);
-        store3(W.ray, W.cap, p, 3, d);
+        rr.ox = o.x, rr.oy = o.y, rr.oz = o.z, rr.dx = d.x, rr.dy = d.y, rr.dz = d.z;
         W.xy[p] = x;
         W.xy[W.cap + p] = y;
         store_rng(W, p, rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot));
@@ -346,6 +421,8 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         W.need[p] = 0;
         store3(W.L, W.cap, p, 0, mk(0.0, 0.0, 0.0));
     }
+    __shared__ uint4 s_tile[kWfBlock * 4];
+    wave_store_rays(W.rays, (uint32_t)p, valid, rr, s_tile + (threadIdx.x >> 6) * 256);
     __shared__ int32_t s_push[kWfBlock / 64 + 1];
     queue_push(W.queue, W.qcount, valid, (int)p, s_push);
 }
@@ -357,13 +434,15 @@ enum { kGather = 0, kShadow = 1 };
 template <int MODE>
 PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V3& o, V3& d, int& skip) {
     if (MODE == kGather) {
-        o = load3(W.ray, W.cap, p, 0);
-        d = load3(W.ray, W.cap, p, 3);
+        const RayRec* rr = W.rays + p;
+        o = mk(rr->ox, rr->oy, rr->oz);
+        d = mk(rr->dx, rr->dy, rr->dz);
         skip = -1;
     } else {
-        const int light = W.light[p];
+        const VertexRec v = W.verts[(size_t)gi * W.cap + p];
+        const int light = v.shadow;
         const V3 lc = light_origin(S, light);
-        V3 Pt = load3(W.pts, W.cap, p, gi * 3);
+        V3 Pt = mk(v.x, v.y, v.z);
         o = lc;
         d = normalize(sub(Pt, lc));  // next_event.cpp:405-407
         skip = light;
@@ -419,26 +498,12 @@ PTD_INLINE uint32_t ray_key(const DScene& S, V3 o, V3 d) {
     return dir * (kKeyOrg * kKeyOrg * kKeyOrg) + ((cz * kKeyOrg + cy) * kKeyOrg + cx);
 }
 
-// Keys only, for every entry up to the capacity of the queue: entries past its count get the
-// largest 16-bit key and sort to the end (the library sort takes its size from the host, which does
-// not know the count).
+// The stage that fills a queue stores every entry's key at its queue position (k_wf_shade,
+// k_wf_light); the key buffers are first filled with ones, so entries past the queue's count carry
+// the largest 16-bit key and sort to the end (the library sort takes its size from the host, which
+// does not know the count).
 constexpr uint32_t kSortKeyBits = PT_KEY_BITS;
 static_assert(6ull * PT_KEY_D * PT_KEY_D * PT_KEY_O * PT_KEY_O * PT_KEY_O < (1ull << PT_KEY_BITS) - 1, "gather keys must stay below the end key");
-template <int MODE>
-__global__ void __launch_bounds__(kWfBlock) k_wf_ray_keys(DScene S, WfState W, int qi, int gi, int cap) {
-    const int count = W.qcount[qi];
-    const int i = blockIdx.x * kWfBlock + threadIdx.x;
-    if (i >= cap) return;
-    uint32_t key = (1u << kSortKeyBits) - 1u;
-    if (i < count) {
-        const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
-        V3 o, d;
-        int skip;
-        queue_ray<MODE>(S, W, p, gi, o, d, skip);
-        key = ray_key<MODE>(S, o, d);
-    }
-    W.keys[i] = key;
-}
 
 // One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.
 // One wave to a block: nothing is shared between waves, and a block of one ends as soon as its
@@ -455,8 +520,15 @@ __global__ void __launch_bounds__(kExtBlock) k_wf_extend(DScene S, WfState W, in
     queue_ray<MODE>(S, W, p, gi, o, d, skip);
     double mint;
     const int hit = nearest_hit_grouped(S, o, d, skip, mint);
-    W.hit[p] = hit;
-    W.t[p] = mint;
+    if (MODE == kGather) {
+        struct alignas(16) Tail {
+            double t;
+            int32_t hit, pad;
+        } tail = {mint, hit, 0};
+        *reinterpret_cast<Tail*>(&W.rays[p].t) = tail;  // one 16-byte store into the line just read
+    } else {
+        W.verts[(size_t)gi * W.cap + p].shadow = hit;
+    }
 }
 
 // Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.  KEYS: the sort key of
@@ -467,32 +539,37 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_shade(DScene S, WfState W, in
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kPushBlock + threadIdx.x;
     if ((int)(blockIdx.x * kPushBlock) >= count) return;
+    __shared__ uint4 s_tile[kPushBlock * 4];  // 64 bytes per thread: the waves' record tiles
+    uint4* tile = s_tile + (threadIdx.x >> 6) * 256;
     bool alive = false;
     size_t p = 0;
     V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 0.0);
+    if (i < count) p = (size_t)W.queue[(size_t)qi * W.cap + i];
+    RayRec rr = wave_load_rays(W.rays, (uint32_t)p, i < count, tile);
+    VertexRec v;
+    v.x = v.y = v.z = 0.0, v.body = -1, v.shadow = -1;
     if (i < count) {
-        p = (size_t)W.queue[(size_t)qi * W.cap + i];
-        const int hit = W.hit[p];
+        const int hit = rr.hit;
         if (hit >= 0) {
             alive = true;
-            o = load3(W.ray, W.cap, p, 0);
-            d = load3(W.ray, W.cap, p, 3);
+            o = mk(rr.ox, rr.oy, rr.oz);
+            d = mk(rr.dx, rr.dy, rr.dz);
             Draws dr;
             dr.rng = load_rng(W, p);
             dr.count = 0;
             const DMat& m = S.mat[hit];
             // the vertex before this one: the ray origin, or the camera-plane point for the first
             const V3 prev = depth > 0 ? o : cam_point(S, W.xy[p], W.xy[W.cap + p]);
-            V3 point = shade_hit(S.geom[hit], m, dr, o, d, W.t[p]);
+            V3 point = shade_hit(S.geom[hit], m, dr, o, d, rr.t);
             if (m.emits | ((m.material != kDiffuse) & same_point(point, prev))) W.need[p] = depth + 1;  // see trace_path_nee_compact
-            store3(W.pts, W.cap, p, depth * 3, point);
-            W.bod[(size_t)depth * W.cap + p] = hit;
+            v.x = point.x, v.y = point.y, v.z = point.z, v.body = hit;
             W.nrec[p] = depth + 1;
-            store3(W.ray, W.cap, p, 0, o);
-            store3(W.ray, W.cap, p, 3, d);
+            rr.ox = o.x, rr.oy = o.y, rr.oz = o.z, rr.dx = d.x, rr.dy = d.y, rr.dz = d.z;  // t and hit go stale; the next scan rewrites them
             store_rng(W, p, dr.rng);
         }
     }
+    wave_store_rays<3>(W.rays, (uint32_t)p, alive, rr, tile);
+    wave_store_verts(W.verts + (size_t)depth * W.cap, (uint32_t)p, alive, v, tile);
     __shared__ int32_t s_push[kPushBlock / 64 + 1];
     const int pos = queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
     if (KEYS && alive) W.keys[pos] = ray_key<kGather>(S, o, d);
@@ -504,6 +581,9 @@ constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks
 // In a scene whose direct term is dead (DScene::nee_emission_only) the colour recurrence starts at
 // zero and stays there until the deepest emitting vertex, so only vertices 0..need-1 get a shadow
 // ray; otherwise every recorded vertex does.
+// KEYS: the sort key of every shadow ray is stored at its queue position (W.skeys was filled with the
+// end key), so the shadow scans' sorts need no pass over the vertices.
+template <bool KEYS>
 __global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
     const int count = W.qcount[0];
     const int i = blockIdx.x * kPushBlock + threadIdx.x;
@@ -511,18 +591,32 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
     const bool active = i < count;
     size_t p = 0;
     int tasks = 0;
+    int light = 0;
     if (active) {
         p = (size_t)W.queue[i];
         Draws dr;
         dr.rng = load_rng(W, p);
         dr.count = 0;
-        W.light[p] = pick_light(S, dr);
+        light = pick_light(S, dr);
+        W.light[p] = light;
         store_rng(W, p, dr.rng);
         tasks = S.nee_emission_only ? W.need[p] : W.nrec[p];
     }
     __shared__ int32_t s_push[kPushBlock / 64 + 1];
-    for (int g = 0; g < kMaxDepth; ++g)
-        queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, tasks > g, (int)p, s_push);
+    for (int g = 0; g < kMaxDepth; ++g) {
+        const bool task = tasks > g;
+        uint32_t key = 0;
+        if (task) {
+            VertexRec* v = W.verts + (size_t)g * W.cap + p;
+            v->shadow = light;  // what the shadow scan reads
+            if (KEYS) {
+                const V3 lc = light_origin(S, light);
+                key = ray_key<kShadow>(S, lc, normalize(sub(mk(v->x, v->y, v->z), lc)));  // the ray of queue_ray<kShadow>
+            }
+        }
+        const int pos = queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, task, (int)p, s_push);
+        if (KEYS && task) W.skeys[(size_t)g * W.cap + pos] = key;
+    }
 }
 
 // NEE vertex gi for the paths of its shadow-task queue.
@@ -533,15 +627,16 @@ __global__ void __launch_bounds__(kWfBlock, 4) k_wf_nee(DScene S, WfState W, int
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
     if (i >= count) return;
     const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
-    const int hit = W.hit[p];
-    if (hit != W.bod[(size_t)gi * W.cap + p]) return;  // occluded: vertex skipped, next_event.cpp:428-430
+    const VertexRec v = W.verts[(size_t)gi * W.cap + p];
+    const int hit = v.shadow;  // what the shadow scan of this vertex hit
+    if (hit != v.body) return;  // occluded: vertex skipped, next_event.cpp:428-430
     const int light = W.light[p];
     const V3 lc = light_origin(S, light);
-    V3 Pt = load3(W.pts, W.cap, p, gi * 3);
+    V3 Pt = mk(v.x, v.y, v.z);
     V3 bd = normalize(sub(Pt, lc));
     V3 next_point;
     if (gi >= 1)
-        next_point = load3(W.pts, W.cap, p, (gi - 1) * 3);
+        next_point = mk(W.verts[(size_t)(gi - 1) * W.cap + p].x, W.verts[(size_t)(gi - 1) * W.cap + p].y, W.verts[(size_t)(gi - 1) * W.cap + p].z);
     else
         next_point = cam_point(S, W.xy[p], W.xy[W.cap + p]);  // camera.getPoint(x, y) next_event.cpp:446
     Draws dr;
@@ -565,7 +660,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_finish(DScene S, WfState W, dou
         // trace(next)*color + emission, deepest hit first (main.cpp:404)
         L = mk(0.0, 0.0, 0.0);
         for (int k = W.nrec[p] - 1; k >= 0; --k) {
-            DMat m = S.mat[W.bod[(size_t)k * W.cap + p]];
+            DMat m = S.mat[W.verts[(size_t)k * W.cap + p].body];
             if (S.flags & 2u) L = add(L, mk(0.0, 0.0, 0.0));  // raytrace3.cpp:840, see trace_path
             L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
         }

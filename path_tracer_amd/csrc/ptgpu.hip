@@ -1159,30 +1159,28 @@ int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     const size_t cap = J * (size_t)s->wf_batch;
     if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
-    // doubles: ray 6, xy 2, pts 15, L 3, t 1 = 27; 32-bit words: rng 4, hit 1, bod 5, nrec 1, light 1, need 1,
-    // queue 11, sorted 1, keys 1 = 26; plus the 16 queue counters
-    size_t bytes = cap * (27 * sizeof(double) + 26 * sizeof(int32_t)) + 16 * sizeof(int32_t);
+    // per path: a ray record, kMaxDepth vertex records; doubles: xy 2, L 3; 32-bit words: rng 4, nrec 1, light 1,
+    // need 1, queue 11, sorted 1, keys 1 + 5 = 25; plus the 16 queue counters
+    size_t bytes = cap * (sizeof(ptw::RayRec) + kMaxDepth * sizeof(ptw::VertexRec) + 5 * sizeof(double) + 25 * sizeof(int32_t)) +
+                   16 * sizeof(int32_t);
     int rc = s->d_wf.ensure(bytes);
     if (rc) return rc;
     ptw::WfState& W = s->wf;
-    double* d = (double*)s->d_wf.p;
-    W.ray = d;
-    W.xy = W.ray + 6 * cap;
-    W.pts = W.xy + 2 * cap;
-    W.L = W.pts + 15 * cap;
-    W.t = W.L + 3 * cap;
-    uint32_t* u = (uint32_t*)(W.t + cap);
+    W.rays = (ptw::RayRec*)s->d_wf.p;  // 256-byte aligned, like every allocation
+    W.verts = (ptw::VertexRec*)(W.rays + cap);
+    W.xy = (double*)(W.verts + cap * kMaxDepth);
+    W.L = W.xy + 2 * cap;
+    uint32_t* u = (uint32_t*)(W.L + 3 * cap);
     W.rng = u;
     int32_t* w = (int32_t*)(u + 4 * cap);
-    W.hit = w;
-    W.bod = W.hit + cap;
-    W.nrec = W.bod + 5 * cap;
+    W.nrec = w;
     W.light = W.nrec + cap;
     W.need = W.light + cap;
     W.queue = W.need + cap;
     W.qcount = W.queue + 11 * cap;
     W.sorted = W.qcount + 16;
     W.keys = (uint32_t*)(W.sorted + cap);
+    W.skeys = W.keys + cap;
     W.cap = cap;
     // the ray sort (rocprim radix sort of 16-bit keys with the path ids as values)
     size_t tmp = 0;
@@ -1209,12 +1207,11 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
     auto sorted_list = [&](int mode, int qi, int gi) -> const int32_t* {
         if (!s->wf_sort) return W.queue + (size_t)qi * W.cap;
-        if (mode == kShadow)
-            hipLaunchKernelGGL((k_wf_ray_keys<kShadow>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, qi, gi, cap);
+        const uint32_t* keys_in = mode == kShadow ? W.skeys + (size_t)gi * W.cap : W.keys;
         uint32_t* keys_out = (uint32_t*)s->d_wf_sort.p;
         void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
         size_t tmp_bytes = s->wf_sort_tmp_bytes;
-        (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, W.keys, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)cap, 0u,
+        (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)cap, 0u,
                                         kSortKeyBits, st);  // errors surface at hipGetLastError below
         return W.sorted;
     };
@@ -1229,7 +1226,12 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         }
     }
     if (s->estimator == PT_EST_NEE) {
-        hipLaunchKernelGGL(k_wf_light, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
+        if (s->wf_sort) {
+            HIP_TRY(hipMemsetAsync(W.skeys, 0xFF, (size_t)kMaxDepth * W.cap * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_wf_light<true>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
+        } else {
+            hipLaunchKernelGGL(k_wf_light<false>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
+        }
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
             const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi);
             hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list);
