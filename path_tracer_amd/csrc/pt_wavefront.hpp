@@ -505,16 +505,17 @@ PTD_INLINE uint32_t ray_key(const DScene& S, V3 o, V3 d) {
 constexpr uint32_t kSortKeyBits = PT_KEY_BITS;
 static_assert(6ull * PT_KEY_D * PT_KEY_D * PT_KEY_O * PT_KEY_O * PT_KEY_O < (1ull << PT_KEY_BITS) - 1, "gather keys must stay below the end key");
 
-// One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.
+// One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.  The
+// first n_sorted entries are taken in the order of `sorted`, the rest in the queue's own.
 // One wave to a block: nothing is shared between waves, and a block of one ends as soon as its
 // own rays are done.
 constexpr int kExtBlock = 64;
 template <int MODE>
-__global__ void __launch_bounds__(kExtBlock) k_wf_extend(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ list) {
+__global__ void __launch_bounds__(kExtBlock) k_wf_extend(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ sorted, int n_sorted) {
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kExtBlock + threadIdx.x;
     if (i >= count) return;
-    const size_t p = (size_t)list[i];  // queue qi, possibly reordered
+    const size_t p = (size_t)(i < n_sorted ? sorted[i] : W.queue[(size_t)qi * W.cap + i]);
     V3 o, d;
     int skip;
     queue_ray<MODE>(S, W, p, gi, o, d, skip);

@@ -515,6 +515,10 @@ struct pt_scene {
     DevBuf d_wf;       // one allocation carved into the wavefront state arrays
     DevBuf d_wf_sort;  // the ray sort: sorted keys (unused afterwards) and the library's temporary storage
     size_t wf_sort_tmp_bytes = 0;
+    // Queue counts of an earlier batch, copied to pinned host memory without waiting for them, and the
+    // capacity they refer to: a hint for how much of a queue is worth sorting (see render_wavefront).
+    int32_t* wf_counts_host = nullptr;
+    int wf_counts_cap = 0;
     ptw::WfState wf;
 };
 
@@ -1187,6 +1191,11 @@ int ensure_wavefront_buffers(pt_scene* s) {
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, W.keys, W.keys, W.queue, W.sorted, cap, 0u, ptw::kSortKeyBits, (hipStream_t)0));
     s->wf_sort_tmp_bytes = tmp;
     if ((rc = s->d_wf_sort.ensure(cap * sizeof(uint32_t) + ((tmp + 255) & ~(size_t)255) + 256))) return rc;
+    if (!s->wf_counts_host) {
+        HIP_TRY(hipHostMalloc((void**)&s->wf_counts_host, 16 * sizeof(int32_t), hipHostMallocDefault));
+        for (int k = 0; k < 16; ++k) s->wf_counts_host[k] = -1;
+    }
+    s->wf_counts_cap = 0;  // no counts for this capacity yet
     return PT_OK;
 }
 
@@ -1205,19 +1214,36 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     // leave k_wf_generate in pixel order)
     // (the keys of a gather queue were written by the shading stage that filled it)
     const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
-    auto sorted_list = [&](int mode, int qi, int gi) -> const int32_t* {
-        if (!s->wf_sort) return W.queue + (size_t)qi * W.cap;
+    // The library sort takes its size from the host.  Only the first n entries of a queue are sorted,
+    // n from the count the same queue had in an earlier batch (plus a margin; everything while no
+    // count has arrived): a scan reads entry i from the sorted list when i < n and from the queue
+    // itself otherwise, so any n gives the same results and a poor guess only costs coherence.
+    auto sort_size = [&](int qi) -> int {
+        if (const char* f = getenv("PTGPU_SORT_FRACTION"))  // tests: a fixed part of the capacity, whatever the counts
+            return (int)std::min<double>((double)cap, std::max(0.0, atof(f)) * (double)cap);
+        const int before = s->wf_counts_host ? s->wf_counts_host[qi] : -1;  // may change under us; any value will do
+        if (before < 0 || s->wf_counts_cap <= 0) return cap;
+        const double frac = (double)before / (double)s->wf_counts_cap;
+        return (int)std::min<double>((double)cap, frac * 1.03 * (double)cap + 4096.0);
+    };
+    auto sorted_list = [&](int mode, int qi, int gi, int* n_sorted) -> const int32_t* {
+        *n_sorted = 0;
+        if (!s->wf_sort) return W.sorted;
+        const int n = sort_size(qi);
         const uint32_t* keys_in = mode == kShadow ? W.skeys + (size_t)gi * W.cap : W.keys;
         uint32_t* keys_out = (uint32_t*)s->d_wf_sort.p;
         void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
         size_t tmp_bytes = s->wf_sort_tmp_bytes;
-        (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)cap, 0u,
+        (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)n, 0u,
                                         kSortKeyBits, st);  // errors surface at hipGetLastError below
+        *n_sorted = n;
         return W.sorted;
     };
     for (int depth = 0; depth < kMaxDepth; ++depth) {
-        const int32_t* list = depth == 0 ? W.queue : sorted_list(kGather, depth, 0);
-        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list);
+        int n_sorted = 0;
+        const int32_t* list = W.sorted;
+        if (depth > 0) list = sorted_list(kGather, depth, 0, &n_sorted);  // the primary rays stay in pixel order
+        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list, n_sorted);
         if (s->wf_sort && depth + 1 < kMaxDepth) {  // the next queue will be sorted: end keys everywhere, then the survivors' keys
             HIP_TRY(hipMemsetAsync(W.keys, 0xFF, (size_t)cap * sizeof(uint32_t), st));
             hipLaunchKernelGGL(k_wf_shade<true>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
@@ -1233,8 +1259,9 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
             hipLaunchKernelGGL(k_wf_light<false>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W);
         }
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
-            const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi);
-            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list);
+            int n_sorted = 0;
+            const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi, &n_sorted);
+            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list, n_sorted);
             if (s->has_measured)
                 hipLaunchKernelGGL((k_wf_nee<true, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
             else
@@ -1245,6 +1272,20 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         hipLaunchKernelGGL((k_wf_finish<kEstPT>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
     }
     HIP_TRY(hipGetLastError());
+    if (s->wf_counts_host && (s->wf_counts_cap == 0 || s->wf_counts_cap == cap)) {  // (a shorter last batch is no measure)
+        HIP_TRY(hipMemcpyAsync(s->wf_counts_host, W.qcount, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        s->wf_counts_cap = cap;
+    }
+    if (getenv("PTGPU_PRINT_QCOUNTS")) {  // development: the queue counts of this batch
+        int32_t qc[16];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(qc, W.qcount, sizeof qc, hipMemcpyDeviceToHost));
+        fprintf(stderr, "batch of %d paths: gather", cap);
+        for (int k = 0; k <= kMaxDepth; ++k) fprintf(stderr, " %d", qc[k]);
+        fprintf(stderr, "; shadow");
+        for (int k = 0; k < kMaxDepth; ++k) fprintf(stderr, " %d", qc[kShadowQueue0 + k]);
+        fprintf(stderr, "\n");
+    }
     return PT_OK;
 }
 
@@ -1376,6 +1417,7 @@ int pt_scene_destroy(pt_scene* s) {
     s->d_accum.release();
     s->d_wf.release();
     s->d_wf_sort.release();
+    if (s->wf_counts_host) (void)hipHostFree(s->wf_counts_host);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
     return PT_OK;

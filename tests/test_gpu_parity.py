@@ -442,6 +442,13 @@ def test_visiting_order_of_the_scan_is_invisible(monkeypatch):
         r.close()
     assert same_bits(out[0][0], out[1][0]) and np.count_nonzero(out[0][0]) > 0.3 * out[0][0].size
     assert np.array_equal(out[0][1], out[1][1]) and same_bits(out[0][2], out[1][2])
+    # Likewise the ray sort: only the leading part of a queue is sorted (as much as an earlier batch
+    # filled), the rest is scanned in queue order.  With a fixed part sorted, or nothing at all:
+    for fraction in ("0.4", "0"):
+        monkeypatch.setenv("PTGPU_SORT_FRACTION", fraction)
+        r = pt.Renderer(pt.preset("synthetic10k", W, H, seed=6))
+        assert same_bits(r.render(0, n_it), out[0][0]), fraction
+        r.close()
 
 
 def test_drop_in_executables_write_the_reference_ppm(port, tmp_path):
