@@ -1,17 +1,19 @@
 // Wavefront form of the estimator for scenes too large for the fused kernel: path state lives in
-// HBM (structure of arrays), each stage is its own kernel over a compacted queue of live paths,
-// and the nearest-hit scan walks a bounding hierarchy of the spheres with scalar loads.
+// HBM (a ray record and vertex records per path, columns for the rest), each stage is its own
+// kernel over a compacted queue of live paths, and the nearest-hit scan walks a bounding hierarchy
+// of the spheres with scalar loads.
 //
 //   k_wf_generate        camera rays, per-path RNG streams, queue 0
 //   k_wf_extend<GATHER>  nearest hit of the current ray           (main.cpp:372-383)
-//   k_wf_shade           point / normal / bounce / offset / record (main.cpp:391-403), queue d+1
-//   k_wf_light           light pick                                (next_event.cpp:390)
+//   k_wf_shade           point / normal / bounce / offset / record (main.cpp:391-403), queue d+1 and its sort keys
+//   k_wf_light           light pick                                (next_event.cpp:390), shadow queues and their sort keys
 //   k_wf_extend<SHADOW>  nearest hit of the shadow ray, light excluded (next_event.cpp:405-426)
 //   k_wf_nee             visibility test + colour recurrence      (next_event.cpp:428-463)
 //   k_wf_finish          Horner (PT) / store the sample
+// Between a queue's filling and its scan the host queues one radix sort of (key, path id) pairs.
 //
 // A path that leaves the scene is not pushed to the next queue, so later stages run on dense
-// waves only (wave64 ballot + one atomic per wave).  Queue d+1 holds the paths with more than d
+// waves only (wave64 ballot, one atomic per block).  Queue d+1 holds the paths with more than d
 // recorded vertices; k_wf_light fills one shadow-task queue per vertex, which the NEE stages
 // walk deepest vertex first.  The arithmetic of every
 // stage is the same device code the fused kernel uses, so both pipelines give identical bits.
