@@ -448,8 +448,9 @@ static v3 radiance_pt(const por_scene* s, draws* d, v3 o, v3 dir) {
     return L;
 }
 
+#define POR_MAX_LIGHTS 65536 /* the reference's list is a std::vector; more than this many is reported, not cut */
 typedef struct lightlist {
-    int idx[64];
+    int idx[POR_MAX_LIGHTS];
     int count;
 } lightlist;
 
@@ -460,7 +461,11 @@ static lightlist find_lights(const por_scene* s) {
     for (int i = 0; i < s->body_count; i++) {
         const double* e = s->bodies[i].emission;
         if ((e[0] >= 1.0L) || (e[1] >= 1.0L) || (e[2] >= 1.0L)) {
-            if (l.count < 64) l.idx[l.count++] = i;
+            if (l.count >= POR_MAX_LIGHTS) {
+                fprintf(stderr, "oracle: more than %d lights\n", POR_MAX_LIGHTS);
+                abort();
+            }
+            l.idx[l.count++] = i;
         }
     }
     return l;

@@ -1749,6 +1749,8 @@ int pt_intersect_all(pt_scene* s, const double* rays6, int n, double* t_all) {
 int pt_trace_paths(pt_scene* s, const int32_t* it_idx2, const double* xy, int n, double* rgb, int32_t* nrec,
                    int32_t* bodies, double* points, int32_t* visible, int32_t* used) {
     if (!s || !it_idx2 || !xy || n < 0) return fail(PT_ERR_INVALID, "pt_trace_paths: bad argument");
+    if ((int)s->bodies.size() > kMaxBodiesFused)
+        return fail(PT_ERR_UNSUPPORTED, "pt_trace_paths: per-path diagnostics run the fused estimator, at most 127 bodies");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(s->device));
     int rc = check_measured_tables(s);
@@ -1789,6 +1791,8 @@ int pt_trace_brdf_indices(pt_scene* s, const int32_t* it_idx2, const double* xy,
     if (!s || !it_idx2 || !xy || !ind || n < 0) return fail(PT_ERR_INVALID, "pt_trace_brdf_indices: bad argument");
     if (s->estimator != PT_EST_NEE || !s->has_measured)
         return fail(PT_ERR_INVALID, "pt_trace_brdf_indices: the scene has no measured body under next-event estimation");
+    if ((int)s->bodies.size() > kMaxBodiesFused)
+        return fail(PT_ERR_UNSUPPORTED, "pt_trace_brdf_indices: per-path diagnostics run the fused estimator, at most 127 bodies");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(s->device));
     int rc = check_measured_tables(s);

@@ -425,6 +425,24 @@ def test_ten_thousand_bodies_across_many_blocks(port):
     r.close()
 
 
+def test_large_random_scenes_with_many_lights(port):
+    """Random scenes of several hundred to a few thousand bodies under next-event estimation: a tenth
+    of the spheres are lights (more than a hundred), shadow rays start at the lights' centres in every
+    other scene, glass and chrome among the bodies.  Wavefront pipeline against the oracle, bit for bit."""
+    W, H = 48, 30
+    for seed in (6015, 6017, 6011):
+        d = random_scene(seed, W, H, 3000)
+        d.flags = seed % 2
+        assert d.estimator == pt.EST_NEE and d.body_count > 127
+        r = pt.Renderer(d)
+        s = oracle_scene(port, r, W, H, seed, flags=d.flags)
+        want, _ = port.render(s, MODE_PIXEL, 0, 3)
+        assert same_bits(r.render(0, 3), want), seed
+        with pytest.raises(pt.PtError):  # the per-path diagnostics are the fused estimator's
+            r.trace_paths(np.zeros((1, 2), dtype=np.int32), np.zeros((1, 2)))
+        r.close()
+
+
 def test_visiting_order_of_the_scan_is_invisible(monkeypatch):
     """The grouped scan visits the top of its hierarchy nearest first from a table built at upload;
     scenes too large for the table are visited in index order.  PTGPU_INDEX_ORDER selects that path
