@@ -443,6 +443,22 @@ def test_large_random_scenes_with_many_lights(port):
         r.close()
 
 
+def test_forty_thousand_bodies(port):
+    """Scenes beyond the 64 section halves the visiting-order table covers (35 000 and 38 000
+    spheres, 3 500 lights): index order at the top of the hierarchy, both estimators, a frame small
+    enough for the oracle."""
+    W, H = 12, 8
+    for seed in (8002, 8001):
+        d = random_scene(seed, W, H, 40000)
+        d.flags = seed % 2
+        assert d.body_count > 33000
+        r = pt.Renderer(d)
+        s = oracle_scene(port, r, W, H, seed, flags=d.flags)
+        want, _ = port.render(s, MODE_PIXEL, 0, 2)
+        assert same_bits(r.render(0, 2), want), seed
+        r.close()
+
+
 def test_visiting_order_of_the_scan_is_invisible(monkeypatch):
     """The grouped scan visits the top of its hierarchy nearest first from a table built at upload;
     scenes too large for the table are visited in index order.  PTGPU_INDEX_ORDER selects that path
