@@ -453,20 +453,22 @@ PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V
 
 // Rays are reordered before a scan so that the 64 rays of a wave start near one another and
 // point the same way: a wave then enters few of the body groups.  The key is a cell of the
-// direction (cube face, 4x4) and a cell of the origin (8x8x8 over the box of the sphere centres);
-// shadow rays, which share their origin, use a fine direction cell (cube face, 64x64).  (Measured
-// on the 10 000-body scene: 8x8 / 5^3 2.48e8, 8x8 / 8^3 2.57e8, 16x16 / 8^3 2.29e8, 4x4 / 8^3 2.71e8,
-// 3x3 / 10^3 2.72e8, 2x2 / 12^3 2.68e8, faces only / 16^3 2.54e8 paths/s.)  One radix sort of the
-// 16-bit keys per scan (rocprim, path ids as values; stable, so a bin keeps the queue's order).  The
-// order of a queue is invisible in the results.
+// direction (cube face, 4x4) and a cell of the origin (16^3 over the box of the sphere centres), 20
+// bits; shadow rays, which share their origin, use a fine direction cell (cube face, 64x64), 16
+// bits.  One radix sort of the keys per scan (rocprim, path ids as values; stable, so a bin keeps
+// the queue's order, which is pixel order: the more paths a batch holds, the closer together on the
+// screen the 64 rays of a wave).  The order of a queue is invisible in the results.  (Measured on
+// the 10 000-body scene with batches of 2^26 paths: 4x4 / 8^3 7.24e8, 4x4 / 12^3 7.31e8, 4x4 / 16^3
+// 7.45e8, 4x4 / 32^3 7.47e8, 8x8 / 32^3 7.23e8, 2x2 / 32^3 7.37e8 paths/s; sorting on the upper 8 or 12
+// bits of a 16-bit key alone: 3.9e8 and 4.9e8 against 6.8e8.)
 #ifndef PT_KEY_D
 #define PT_KEY_D 4
 #endif
 #ifndef PT_KEY_O
-#define PT_KEY_O 8
+#define PT_KEY_O 16
 #endif
 #ifndef PT_KEY_BITS
-#define PT_KEY_BITS 16
+#define PT_KEY_BITS 20
 #endif
 constexpr int kKeyDir = PT_KEY_D, kKeyOrg = PT_KEY_O;
 template <int MODE>
@@ -502,10 +504,12 @@ PTD_INLINE uint32_t ray_key(const DScene& S, V3 o, V3 d) {
 
 // The stage that fills a queue stores every entry's key at its queue position (k_wf_shade,
 // k_wf_light); the key buffers are first filled with ones, so entries past the queue's count carry
-// the largest 16-bit key and sort to the end (the library sort takes its size from the host, which
-// does not know the count).
-constexpr uint32_t kSortKeyBits = PT_KEY_BITS;
+// the largest key of the sorted bits and sort to the end (the library sort takes its size from the
+// host, which does not know the count).
+constexpr uint32_t kSortKeyBits = PT_KEY_BITS;  // gather rays
+constexpr uint32_t kShadowKeyBits = 16;         // shadow rays: 6 * 64 * 64 cells
 static_assert(6ull * PT_KEY_D * PT_KEY_D * PT_KEY_O * PT_KEY_O * PT_KEY_O < (1ull << PT_KEY_BITS) - 1, "gather keys must stay below the end key");
+static_assert(6ull * 64 * 64 < (1ull << kShadowKeyBits) - 1, "shadow keys must stay below the end key");
 
 // One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.  The
 // first n_sorted entries are taken in the order of `sorted`, the rest in the queue's own.

@@ -543,15 +543,23 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
     size_t b = ((size_t)1 << 24) / per_it;
     s->batch = (int)std::min<size_t>(128, std::max<size_t>(1, b));
-    // the wavefront pipeline keeps ~320 B of state per path in HBM (5.3 GB at 2^24 paths); large
-    // batches also put more rays into every cell of the ray sort
-    size_t wb = ((size_t)1 << 24) / per_it;
-    s->wf_batch = (int)std::min<size_t>((size_t)s->batch, std::max<size_t>(1, wb));
+    // the wavefront pipeline keeps 364 B of state per path in HBM: batches of 2^26 paths (24 GB, with
+    // the samples 28 GB of the 288) — the more paths, the more coherent the waves the ray sort
+    // forms (2^24: 6.85e8, 2^25: 7.09e8, 2^26: 7.19e8, 2^27: 7.28e8 paths/s on the 10 000-body scene)
+    size_t wb = ((size_t)1 << 26) / per_it;
+    s->wf_batch = (int)std::min<size_t>(128, std::max<size_t>(1, wb));
     return PT_OK;
 }
 
+constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
+
+// Which pipeline pt_render_device runs (see pt_set_pipeline).
+bool uses_wavefront(const pt_scene* s) {
+    return s->pipeline == PT_PIPELINE_WAVEFRONT || (s->pipeline == PT_PIPELINE_AUTO && (int)s->bodies.size() > kMaxBodiesFused);
+}
+
 int ensure_render_buffers(pt_scene* s) {
-    const size_t W = s->width, H = s->height, B = s->batch;
+    const size_t W = s->width, H = s->height, B = (size_t)(uses_wavefront(s) ? s->wf_batch : s->batch);
     int rc;
     size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     for (int k = 0; k < 2; ++k) {
@@ -574,7 +582,6 @@ int ensure_render_buffers(pt_scene* s) {
     return PT_OK;
 }
 
-constexpr int kMaxBodiesFused = 127;  // body indices are kept as int8 in the fused kernel's LDS records
 
 // Builds and uploads everything the kernels read about a scene: body and material records, the
 // compact scan lists with their slabs, the grouped layout of the large-scene scan, the rectangle list, the
@@ -1235,7 +1242,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
         size_t tmp_bytes = s->wf_sort_tmp_bytes;
         (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)n, 0u,
-                                        kSortKeyBits, st);  // errors surface at hipGetLastError below
+                                        mode == kShadow ? kShadowKeyBits : kSortKeyBits, st);  // errors surface at hipGetLastError below
         *n_sorted = n;
         return W.sorted;
     };
@@ -1542,8 +1549,7 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     const int W = s->width, H = s->height;
     const size_t J = (size_t)P.owned_tiles * kBlock;
     int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
-    const bool use_wavefront = s->pipeline == PT_PIPELINE_WAVEFRONT ||
-                               (s->pipeline == PT_PIPELINE_AUTO && (int)s->bodies.size() > kMaxBodiesFused);
+    const bool use_wavefront = uses_wavefront(s);
     if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
     const int batch = use_wavefront ? s->wf_batch : s->batch;
