@@ -8,14 +8,14 @@
 //   k_wf_shade           point / normal / bounce / offset / record (main.cpp:391-403), queue d+1 and its sort keys
 //   k_wf_light           light pick                                (next_event.cpp:390), shadow queues and their sort keys
 //   k_wf_extend<SHADOW>  nearest hit of the shadow ray, light excluded (next_event.cpp:405-426)
-//   k_wf_nee             visibility test + colour recurrence      (next_event.cpp:428-463)
-//   k_wf_finish          Horner (PT) / store the sample
+//   k_wf_nee_finish      visibility tests + colour recurrence     (next_event.cpp:428-463), the sample
+//   k_wf_finish          plain path tracing: Horner, the sample
 // Between a queue's filling and its scan the host queues one radix sort of (key, path id) pairs.
 //
 // A path that leaves the scene is not pushed to the next queue, so later stages run on dense
 // waves only (wave64 ballot, one atomic per block).  Queue d+1 holds the paths with more than d
-// recorded vertices; k_wf_light fills one shadow-task queue per vertex, which the NEE stages
-// walk deepest vertex first.  The arithmetic of every
+// recorded vertices; k_wf_light fills one shadow-task queue per vertex, one scan each; the colour
+// recurrence then walks a path's vertices deepest first.  The arithmetic of every
 // stage is the same device code the fused kernel uses, so both pipelines give identical bits.
 #pragma once
 #include "pt_device.hpp"
@@ -105,7 +105,6 @@ struct WfState {
     RayRec* rays;      // [cap]
     VertexRec* verts;  // [kMaxDepth][cap]
     double* xy;      // [2][cap]  image-plane coordinates of the sample
-    double* L;       // [3][cap]  running colour
     uint32_t* rng;   // [4][cap]
     int32_t* nrec;   // [cap]
     int32_t* light;  // [cap]
@@ -421,7 +420,6 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         store_rng(W, p, rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot));
         W.nrec[p] = 0;
         W.need[p] = 0;
-        store3(W.L, W.cap, p, 0, mk(0.0, 0.0, 0.0));
     }
     __shared__ uint4 s_tile[kWfBlock * 4];
     wave_store_rays(W.rays, (uint32_t)p, valid, rr, s_tile + (threadIdx.x >> 6) * 256);
@@ -626,53 +624,61 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
     }
 }
 
-// NEE vertex gi for the paths of its shadow-task queue.
-template <bool MEASURED, bool ELIDE>
-__global__ void __launch_bounds__(kWfBlock, 4) k_wf_nee(DScene S, WfState W, int gi) {
-    const int qi = kShadowQueue0 + gi;
-    const int count = W.qcount[qi];
+// The colour recurrence of a path over its lit vertices, deepest first (next_event.cpp:428-463), once
+// all its shadow scans are done, and the sample.  One pass over the paths instead of one per vertex:
+// a per-vertex stage reads the RNG, colour and light columns in full for a queue that holds a third
+// of the paths.
+template <bool MEASURED>
+__global__ void __launch_bounds__(kWfBlock, 4) k_wf_nee_finish(DScene S, WfState W, double* __restrict__ samples, size_t J) {
+    const int count = W.qcount[0];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
     if (i >= count) return;
-    const size_t p = (size_t)W.queue[(size_t)qi * W.cap + i];
-    const VertexRec v = W.verts[(size_t)gi * W.cap + p];
-    const int hit = v.shadow;  // what the shadow scan of this vertex hit
-    if (hit != v.body) return;  // occluded: vertex skipped, next_event.cpp:428-430
-    const int light = W.light[p];
-    const V3 lc = light_origin(S, light);
-    V3 Pt = mk(v.x, v.y, v.z);
-    V3 bd = normalize(sub(Pt, lc));
-    V3 next_point;
-    if (gi >= 1)
-        next_point = mk(W.verts[(size_t)(gi - 1) * W.cap + p].x, W.verts[(size_t)(gi - 1) * W.cap + p].y, W.verts[(size_t)(gi - 1) * W.cap + p].z);
-    else
-        next_point = cam_point(S, W.xy[p], W.xy[W.cap + p]);  // camera.getPoint(x, y) next_event.cpp:446
-    Draws dr;
-    dr.rng = load_rng(W, p);
-    dr.count = 0;
-    V3 L = load3(W.L, W.cap, p, 0);
-    L = nee_vertex<MEASURED, ELIDE>(S, S.geom[hit], S.mat[hit], dr, light, Pt, bd, next_point, L);
-    store3(W.L, W.cap, p, 0, L);
-    store_rng(W, p, dr.rng);
+    const size_t p = (size_t)W.queue[i];
+    const int tasks = S.nee_emission_only ? W.need[p] : W.nrec[p];  // the vertices k_wf_light queued shadow rays for
+    V3 L = mk(0.0, 0.0, 0.0);
+    if (tasks > 0) {
+        const int light = W.light[p];
+        const V3 lc = light_origin(S, light);
+        Draws dr;
+        dr.rng = load_rng(W, p);
+        dr.count = 0;
+#pragma unroll 1
+        for (int gi = tasks - 1; gi >= 0; --gi) {
+            const VertexRec v = W.verts[(size_t)gi * W.cap + p];
+            const int hit = v.shadow;  // what the shadow scan of this vertex hit
+            if (hit != v.body) continue;  // occluded: vertex skipped, next_event.cpp:428-430
+            const V3 Pt = mk(v.x, v.y, v.z);
+            const V3 bd = normalize(sub(Pt, lc));
+            V3 next_point;
+            if (gi >= 1) {
+                const VertexRec* q = W.verts + (size_t)(gi - 1) * W.cap + p;
+                next_point = mk(q->x, q->y, q->z);
+            } else {
+                next_point = cam_point(S, W.xy[p], W.xy[W.cap + p]);  // camera.getPoint(x, y) next_event.cpp:446
+            }
+            L = nee_vertex<MEASURED, true>(S, S.geom[hit], S.mat[hit], dr, light, Pt, bd, next_point, L);
+        }
+    }
+    const size_t b = p / J, j = p % J;
+    double* out = samples + b * 3 * J + j;
+    L = canonical_nan(L);
+    out[0] = L.x;
+    out[J] = L.y;
+    out[2 * J] = L.z;
 }
 
-// Write the sample of every generated path: path id p = b * J + j -> samples[b][c][j].
-template <int EST>
+// Plain path tracing: the sample of every generated path, path id p = b * J + j -> samples[b][c][j].
 __global__ void __launch_bounds__(kWfBlock) k_wf_finish(DScene S, WfState W, double* __restrict__ samples, size_t J) {
     const int count = W.qcount[0];
     const int i = blockIdx.x * kWfBlock + threadIdx.x;
     if (i >= count) return;
     const size_t p = (size_t)W.queue[i];
-    V3 L;
-    if (EST == kEstPT) {
-        // trace(next)*color + emission, deepest hit first (main.cpp:404)
-        L = mk(0.0, 0.0, 0.0);
-        for (int k = W.nrec[p] - 1; k >= 0; --k) {
-            DMat m = S.mat[W.verts[(size_t)k * W.cap + p].body];
-            if (S.flags & 2u) L = add(L, mk(0.0, 0.0, 0.0));  // raytrace3.cpp:840, see trace_path
-            L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
-        }
-    } else {
-        L = load3(W.L, W.cap, p, 0);
+    // trace(next)*color + emission, deepest hit first (main.cpp:404)
+    V3 L = mk(0.0, 0.0, 0.0);
+    for (int k = W.nrec[p] - 1; k >= 0; --k) {
+        DMat m = S.mat[W.verts[(size_t)k * W.cap + p].body];
+        if (S.flags & 2u) L = add(L, mk(0.0, 0.0, 0.0));  // raytrace3.cpp:840, see trace_path
+        L = add(mul(L, mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));
     }
     const size_t b = p / J, j = p % J;
     double* out = samples + b * 3 * J + j;

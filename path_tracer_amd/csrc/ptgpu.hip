@@ -1170,9 +1170,9 @@ int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     const size_t cap = J * (size_t)s->wf_batch;
     if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
-    // per path: a ray record, kMaxDepth vertex records; doubles: xy 2, L 3; 32-bit words: rng 4, nrec 1, light 1,
+    // per path: a ray record, kMaxDepth vertex records; doubles: xy 2; 32-bit words: rng 4, nrec 1, light 1,
     // need 1, queue 11, sorted 1, keys 1 + 5 = 25; plus the 16 queue counters
-    size_t bytes = cap * (sizeof(ptw::RayRec) + kMaxDepth * sizeof(ptw::VertexRec) + 5 * sizeof(double) + 25 * sizeof(int32_t)) +
+    size_t bytes = cap * (sizeof(ptw::RayRec) + kMaxDepth * sizeof(ptw::VertexRec) + 2 * sizeof(double) + 25 * sizeof(int32_t)) +
                    16 * sizeof(int32_t);
     int rc = s->d_wf.ensure(bytes);
     if (rc) return rc;
@@ -1180,8 +1180,7 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.rays = (ptw::RayRec*)s->d_wf.p;  // 256-byte aligned, like every allocation
     W.verts = (ptw::VertexRec*)(W.rays + cap);
     W.xy = (double*)(W.verts + cap * kMaxDepth);
-    W.L = W.xy + 2 * cap;
-    uint32_t* u = (uint32_t*)(W.L + 3 * cap);
+    uint32_t* u = (uint32_t*)(W.xy + 2 * cap);
     W.rng = u;
     int32_t* w = (int32_t*)(u + 4 * cap);
     W.nrec = w;
@@ -1269,14 +1268,13 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
             int n_sorted = 0;
             const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi, &n_sorted);
             hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list, n_sorted);
-            if (s->has_measured)
-                hipLaunchKernelGGL((k_wf_nee<true, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
-            else
-                hipLaunchKernelGGL((k_wf_nee<false, true>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, gi);
         }
-        hipLaunchKernelGGL((k_wf_finish<kEstNEE>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
+        if (s->has_measured)
+            hipLaunchKernelGGL(k_wf_nee_finish<true>, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
+        else
+            hipLaunchKernelGGL(k_wf_nee_finish<false>, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
     } else {
-        hipLaunchKernelGGL((k_wf_finish<kEstPT>), dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
+        hipLaunchKernelGGL(k_wf_finish, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
     }
     HIP_TRY(hipGetLastError());
     if (s->wf_counts_host && (s->wf_counts_cap == 0 || s->wf_counts_cap == cap)) {  // (a shorter last batch is no measure)
