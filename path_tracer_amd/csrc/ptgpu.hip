@@ -511,7 +511,8 @@ struct pt_scene {
     bool has_measured = false;  // any PT_MEASURED body: selects the kernel variant with the table lookup
     bool has_rectangles = false;
     int pipeline = PT_PIPELINE_AUTO;
-    int wf_batch = 1;  // iterations per wavefront batch
+    int wf_batch = 1;  // iterations per wavefront batch, at most
+    int wf_batch_alloc = 0;  // iterations per batch the wavefront and frame buffers are sized for (grows with the calls)
     DevBuf d_wf;       // one allocation carved into the wavefront state arrays
     DevBuf d_wf_sort;  // the ray sort: sorted keys (unused afterwards) and the library's temporary storage
     size_t wf_sort_tmp_bytes = 0;
@@ -548,6 +549,7 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     // forms (2^24: 6.85e8, 2^25: 7.09e8, 2^26: 7.19e8, 2^27: 7.28e8 paths/s on the 10 000-body scene)
     size_t wb = ((size_t)1 << 26) / per_it;
     s->wf_batch = (int)std::min<size_t>(128, std::max<size_t>(1, wb));
+    s->wf_batch_alloc = 0;  // sized again by the next call
     return PT_OK;
 }
 
@@ -559,7 +561,7 @@ bool uses_wavefront(const pt_scene* s) {
 }
 
 int ensure_render_buffers(pt_scene* s) {
-    const size_t W = s->width, H = s->height, B = (size_t)(uses_wavefront(s) ? s->wf_batch : s->batch);
+    const size_t W = s->width, H = s->height, B = (size_t)(uses_wavefront(s) ? std::max(1, s->wf_batch_alloc) : s->batch);
     int rc;
     size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     for (int k = 0; k < 2; ++k) {
@@ -1168,7 +1170,7 @@ int upload_scene(pt_scene* s) { return SceneUpload(s).run(); }
 
 int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
-    const size_t cap = J * (size_t)s->wf_batch;
+    const size_t cap = J * (size_t)s->wf_batch_alloc;
     if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
     // per path: a ray record, kMaxDepth vertex records; doubles: xy 2; 32-bit words: rng 4, nrec 1, light 1,
     // need 1, queue 11, sorted 1, keys 1 + 5 = 25; plus the 16 queue counters
@@ -1538,6 +1540,8 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     HIP_TRY(hipSetDevice(s->device));
     int rc = check_measured_tables(s);
     if (rc) return rc;
+    // a call of few iterations does not need the state of a full batch (23 GB for large scenes)
+    if (uses_wavefront(s)) s->wf_batch_alloc = std::max(s->wf_batch_alloc, std::min(s->wf_batch, std::max(1, n_iterations)));
     if ((rc = ensure_render_buffers(s))) return rc;
     hipStream_t st = (hipStream_t)stream_;
     const Partition P = s->part;
@@ -1550,7 +1554,7 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     const bool use_wavefront = uses_wavefront(s);
     if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
-    const int batch = use_wavefront ? s->wf_batch : s->batch;
+    const int batch = use_wavefront ? s->wf_batch_alloc : s->batch;
     if (use_wavefront && (rc = ensure_wavefront_buffers(s))) return rc;
     const int nbatch = (n_iterations + batch - 1) / batch;
     // Three streams: the caller's stream runs the estimator kernels back to back; the frame layout
