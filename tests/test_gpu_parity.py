@@ -194,6 +194,24 @@ def test_partition_tiles_sum_to_whole():
         assert owned.max() == 1
 
 
+def test_partition_tiles_sum_to_whole_large_scene():
+    """The same for the wavefront pipeline (1 000 bodies), on one handle whose partition changes
+    between renders."""
+    W, H, n_it = 70, 40, 4
+    r = pt.Renderer(pt.preset("synthetic1k", W, H, seed=4))
+    whole = r.render(0, n_it)
+    assert np.count_nonzero(whole) > 0.3 * whole.size
+    for world in (2, 5):
+        acc = np.zeros_like(whole)
+        for rank in range(world):
+            r.set_partition(rank, world)
+            acc += r.render(0, n_it)
+        assert same_bits(acc, whole)
+    r.set_partition(0, 1)
+    assert same_bits(r.render(0, n_it), whole)
+    r.close()
+
+
 def test_true_light_centre_flag(port):
     d = pt.preset("nee15", 48, 32, seed=8)
     d.flags = pt.F_LIGHT_TRUE_CENTER
