@@ -41,6 +41,12 @@ struct alignas(32) VertexRec {  // a recorded vertex: the offset point and its b
     int32_t shadow;  // the path's light (set by k_wf_light) until the vertex's shadow scan stores the body it hit
 };
 
+// Path state is written by one stage and read by a later kernel after gigabytes of other traffic:
+// the stores say so (non-temporal), which leaves the caches to the scene records (+1.5 %).
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+#define PT_NT_STORE(v, ptr) __builtin_nontemporal_store(u32x4_nt{(v).x, (v).y, (v).z, (v).w}, reinterpret_cast<u32x4_nt*>(ptr))
+#define PT_NT1(v, ptr) __builtin_nontemporal_store((v), (ptr))
+
 // A wave that owns one record per lane at arbitrary path ids moves the records four lanes to a
 // record (two for the vertex records), 16 bytes a lane: every load or store instruction then covers
 // whole records instead of a sixteen-byte piece of 64 different ones, which is what the memory
@@ -80,7 +86,7 @@ PTD_INLINE void wave_store_rays(RayRec* __restrict__ rays, uint32_t p, bool on, 
     for (uint32_t r = 0; r < 4; ++r) {
         const uint32_t ps = (uint32_t)__shfl((int)mine, (int)(r * 16u + (lane >> 2)));
         const uint4 v = tile[r * 64u + lane];
-        if (ps != kNoPath && (int)piece < PIECES) reinterpret_cast<uint4*>(rays + ps)[piece] = v;
+        if (ps != kNoPath && (int)piece < PIECES) PT_NT_STORE(v, reinterpret_cast<uint4*>(rays + ps) + piece);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -96,7 +102,7 @@ PTD_INLINE void wave_store_verts(VertexRec* __restrict__ verts, uint32_t index, 
     for (uint32_t r = 0; r < 2; ++r) {
         const uint32_t is = (uint32_t)__shfl((int)mine, (int)(r * 32u + (lane >> 1)));
         const uint4 v = tile[r * 64u + lane];
-        if (is != kNoPath) reinterpret_cast<uint4*>(verts + is)[piece] = v;
+        if (is != kNoPath) PT_NT_STORE(v, reinterpret_cast<uint4*>(verts + is) + piece);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -141,7 +147,7 @@ PTD_INLINE int queue_push(int32_t* q, int32_t* count, bool pred, int value, int3
     }
     __syncthreads();
     const int pos = slots[nwaves] + slots[wave] + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (pred) q[pos] = value;
+    if (pred) PT_NT1(value, q + pos);
     return pred ? pos : -1;
 }
 
@@ -154,10 +160,10 @@ PTD_INLINE Rng load_rng(const WfState& W, size_t p) {
     return r;
 }
 PTD_INLINE void store_rng(const WfState& W, size_t p, const Rng& r) {
-    W.rng[p] = r.s0;
-    W.rng[W.cap + p] = r.s1;
-    W.rng[2 * W.cap + p] = r.s2;
-    W.rng[3 * W.cap + p] = r.s3;
+    PT_NT1(r.s0, W.rng + p);
+    PT_NT1(r.s1, W.rng + W.cap + p);
+    PT_NT1(r.s2, W.rng + 2 * W.cap + p);
+    PT_NT1(r.s3, W.rng + 3 * W.cap + p);
 }
 PTD_INLINE V3 load3(const double* a, size_t cap, size_t p, int first) {
     return mk(a[(size_t)first * cap + p], a[(size_t)(first + 1) * cap + p], a[(size_t)(first + 2) * cap + p]);
@@ -577,7 +583,7 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_shade(DScene S, WfState W, in
     wave_store_verts(W.verts + (size_t)depth * W.cap, (uint32_t)p, alive, v, tile);
     __shared__ int32_t s_push[kPushBlock / 64 + 1];
     const int pos = queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
-    if (KEYS && alive) W.keys[pos] = ray_key<kGather>(S, o, d);
+    if (KEYS && alive) PT_NT1(ray_key<kGather>(S, o, d), W.keys + pos);
 }
 
 constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks of vertex 0
@@ -620,7 +626,7 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
             }
         }
         const int pos = queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, task, (int)p, s_push);
-        if (KEYS && task) W.skeys[(size_t)g * W.cap + pos] = key;
+        if (KEYS && task) PT_NT1(key, W.skeys + (size_t)g * W.cap + pos);
     }
 }
 
