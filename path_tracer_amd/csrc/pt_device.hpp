@@ -13,6 +13,7 @@
 namespace ptd {
 
 #define PTD_INLINE __device__ __forceinline__
+#define PTD_HOST_DEVICE __host__ __device__
 
 // ---- optional section timing (development builds only: -DPT_PROFILE_SECTIONS) -------------
 // PT_PROF(k) times the enclosing scope with the wave's cycle counter and adds the time to a
@@ -884,13 +885,18 @@ PTD_INLINE int brdf_index(double theta_in, double fi_in, double theta_out, doubl
 
 // The values of lookup_brdf_val :68-79 for a table index.  The device copy of a table keeps the
 // red, green and blue value of an index next to each other (24 bytes).
+// The channel scales and the "below the horizon" rule of lookup_brdf_val (:73-78) depend on the
+// table entry alone and are applied once, at upload (brdf_entry): the device table holds final values.
+PTD_HOST_DEVICE inline void brdf_entry(double red, double green, double blue, double* out3) {
+    double r = red * (1.0 / 1500.0);
+    double g = green * (1.15 / 1500.0);
+    double b = blue * (1.66 / 1500.0);
+    if (r < 0.0 || g < 0.0 || b < 0.0) r = g = b = 0.0;
+    out3[0] = r, out3[1] = g, out3[2] = b;
+}
 PTD_INLINE V3 brdf_rgb(const double* __restrict__ table, int ind) {
     const double* e = table + 3 * (size_t)ind;
-    double r = e[0] * (1.0 / 1500.0);
-    double g = e[1] * (1.15 / 1500.0);
-    double b = e[2] * (1.66 / 1500.0);
-    if (r < 0.0 || g < 0.0 || b < 0.0) r = g = b = 0.0;
-    return mk(r, g, b);
+    return mk(e[0], e[1], e[2]);
 }
 // lookup_brdf_val :50-80 from the four angles.
 PTD_INLINE V3 brdf_lookup(const double* __restrict__ table, double theta_in, double fi_in, double theta_out,
@@ -1042,22 +1048,32 @@ constexpr int kBinsHalf = 0, kBinsDiff = 128, kBinsPhi = 256, kBinsTotal = 512;
 
 // Number of edges passed: the largest pos with v <= T[pos] (T[0] counts as passed, T descending,
 // padded with values no v reaches).  NaN passes nothing.
+// The position is kept as a 32-bit byte offset whose bits the steps set one by one, so that a step is
+// a load at (uniform base + offset + constant), a compare, a select and an or.
 template <int SIZE>
-PTD_INLINE int bins_passed(const double* __restrict__ T, double v) {
-    int pos = 0;
+PTD_INLINE uint32_t bins_passed8(const double* __restrict__ T, double v) {  // 8 * the number of edges passed
+    const char* base = reinterpret_cast<const char*>(T);
+    uint32_t off = 0;
 #pragma unroll
-    for (int step = SIZE / 2; step > 0; step >>= 1)
-        if (v <= T[pos + step]) pos += step;
-    return pos;
+    for (uint32_t step = SIZE / 2 * 8; step >= 8; step >>= 1) {
+        const double edge = *reinterpret_cast<const double*>(base + (off + step));
+        off |= v <= edge ? step : 0u;
+    }
+    return off;
 }
 
-// 1/sqrt(x) and 1/x to within an ulp or two: the hardware estimate (2^-26) and two Newton steps.
+// 1/sqrt(x) and 1/x to about two ulps: the hardware estimate (relative error 2^-26) and one Newton
+// step (1.5 e^2 = 3.3e-16, plus the step's own rounding); a second step changed no table index of
+// the tests and costs four instructions per call, seven calls per lookup.
 // 0 gives NaN (0 * inf) where the quotient forms would give 0/0 = NaN or x/0 = inf; callers treat
 // those poles separately.
+#ifndef PT_NR_STEPS
+#define PT_NR_STEPS 1
+#endif
 PTD_INLINE double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PT_NR_STEPS; ++k) {
         const double g = x * y, hh = 0.5 * y;
         const double r = __builtin_fma(-g, hh, 0.5);
         y = __builtin_fma(y, r, y);
@@ -1067,52 +1083,55 @@ PTD_INLINE double rsqrt_nr(double x) {
 PTD_INLINE double rcp_nr(double d) {
     double y = __builtin_amdgcn_rcp(d);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PT_NR_STEPS; ++k) {
         const double e = __builtin_fma(-d, y, 1.0);
         y = __builtin_fma(y, e, y);
     }
     return y;
 }
 
-// cos / sin of theta = atan(y/x) and of phi = acos(z/len) (vector_to_spherical, raytrace3.cpp:725-728)
-PTD_INLINE void spherical_sincos(V3 v, double& ct, double& st, double& cp, double& sp) {
-    const double h2 = v.x * v.x + v.y * v.y;
-    const double ih = rsqrt_nr(h2), il = rsqrt_nr(h2 + v.z * v.z);
-    ct = fabs(v.x) * ih;
-    st = __builtin_copysign(1.0, v.x) * v.y * ih;
-    double c = v.z * il;
-    if (!(fabs(c) <= 1.0)) c = __builtin_nan("");  // acos outside [-1, 1]
-    cp = c;
-    sp = (h2 * ih) * il;  // sqrt(x^2 + y^2) / len
+// The unit vector std_coords_to_half_diff_coords :161-167 builds from the angles vector_to_spherical
+// (raytrace3.cpp:725-728) gives for v: theta = atan(y/x), phi = acos(z/len), and
+//   (sin theta cos phi, sin theta sin phi, cos theta) = (s y z / (h len), s y / len, |x| / h),
+// h = sqrt(x^2 + y^2), s = sign(x)  (sin phi = h/len cancels one h).  The sums and products of this
+// function and the next are fused where the operation count allows: the lookup is exact to the table
+// bin, not to the bit, and a fused operation is the more accurate one.
+PTD_INLINE void spherical_unit(V3 v, double& a0, double& a1, double& a2) {
+    const double h2 = __builtin_fma(v.y, v.y, v.x * v.x);
+    const double ih = rsqrt_nr(h2), il = rsqrt_nr(__builtin_fma(v.z, v.z, h2));
+    const double c = v.z * il;  // the reference's correctly rounded z / len never leaves [-1, 1]
+    const double st = __builtin_copysign(1.0, v.x) * (v.y * ih);
+    a0 = st * c;
+    a1 = (st * h2) * (ih * il);  // NaN with st when h = 0, as atan(0/0) makes every term
+    a2 = fabs(v.x) * ih;
 }
 
 PTD_INLINE int brdf_index_of_vectors(const double* __restrict__ bins, V3 vin, V3 vout) {
-    double ct_i, st_i, cp_i, sp_i, ct_o, st_o, cp_o, sp_o;
-    spherical_sincos(vin, ct_i, st_i, cp_i, sp_i);
-    spherical_sincos(vout, ct_o, st_o, cp_o, sp_o);
+    double in[3], out[3];
+    spherical_unit(vin, in[0], in[1], in[2]);
+    spherical_unit(vout, out[0], out[1], out[2]);
     // std_coords_to_half_diff_coords :159-205.  `in` has unit length up to rounding; the reference's
     // normalisation of it (:169) changes the last place only and is left out.
-    const double in[3] = {st_i * cp_i, st_i * sp_i, ct_i};
-    const double out_vec_x = st_o * cp_o, out_vec_y = st_o * sp_o, out_vec_z = ct_o;
-    // half = normalize((in + out) / 2): the factor 1/2 cancels
-    double half[3] = {in[0] + out_vec_x, in[1] + out_vec_y, in[2] + out_vec_z};
-    const double ihl = rsqrt_nr(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]);
-    half[0] *= ihl;
-    half[1] *= ihl;
-    half[2] *= ihl;
-    const double r2 = half[0] * half[0] + half[1] * half[1];
-    const double ir = rsqrt_nr(r2);
-    double r = r2 * ir;  // sin(theta_half)
-    // rotation by -fi_half about (0,0,1); on the pole (r == 0) atan2 gives 0 or pi
-    double cos1 = half[0] * ir, sin1 = -half[1] * ir;
-    if (r2 == 0.0) {
-        cos1 = __builtin_copysign(1.0, half[0]);
-        sin1 = 0.0;
-        r = 0.0;
-    }
+    // half = normalize((in + out) / 2): the factor 1/2 cancels, and the rotation angles are taken
+    // from the sum before it is normalised
+    double hx = in[0] + out[0];
+    const double hy = in[1] + out[1], hz = in[2] + out[2];
+    const double r2 = __builtin_fma(hy, hy, hx * hx);
+    const double ihl = rsqrt_nr(__builtin_fma(hz, hz, r2));
+    // rotation by -fi_half about (0,0,1); on the pole (r2 == 0, hx and hy zeros) atan2 gives 0 or pi:
+    // cos = the sign of hx, sin = 0.  There the rotation is taken from (sign of hx, hy) and length 1.
+    const bool pole = r2 == 0.0;
+    if (pole) hx = __builtin_copysign(1.0, hx);
+    const double ir = rsqrt_nr(pole ? 1.0 : r2);
+    const double cos1 = hx * ir, sin1 = -hy * ir;
+    const double r = (r2 * ir) * ihl;  // sin(theta_half)
+    double half[3];
+    half[2] = hz * ihl;
     // rotate_vector :133-156 about (0,0,1) by (cos1, sin1), then about (0,1,0) by (half.z, -r);
     // the terms that multiply the zero components of the axes are dropped
     double temp[3];
+    // (not fused: where the two products cancel, as for a direction in a coordinate plane, the
+    // result must be the exact zero that the separate roundings of the reference's form give)
     temp[0] = in[0] * cos1 - in[1] * sin1;
     temp[1] = in[1] * cos1 + in[0] * sin1;
     temp[2] = in[2];
@@ -1122,19 +1141,19 @@ PTD_INLINE int brdf_index_of_vectors(const double* __restrict__ bins, V3 vin, V3
     diff[1] = temp[1];
     diff[2] = temp[2] * cos2 - temp[0] * sin2;
     // theta_half_index(acos(half.z)) :211-223
-    const int i_half = bins_passed<128>(bins + kBinsHalf, half[2]);
+    const uint32_t i_half8 = bins_passed8<128>(bins + kBinsHalf, half[2]);
     // theta_diff_index(acos(diff.z)) :228-237; acos is NaN outside [-1, 1] and NaN indexes bin 0
-    int i_diff = bins_passed<128>(bins + kBinsDiff, diff[2]);
-    if (diff[2] < -1.0) i_diff = 0;
+    uint32_t i_diff8 = bins_passed8<128>(bins + kBinsDiff, diff[2]);
+    if (diff[2] < -1.0) i_diff8 = 0;
     // phi_diff_index(atan2(diff.y, diff.x)) :241-257: the angle is taken modulo pi, so it depends on
     // cot = x/y alone; y == 0 gives 0 or pi, and pi stays pi (bin 179) only for y = +0 with x
     // negative (or -0), -pi being moved to 0.
-    int i_phi;
+    uint32_t i_phi8;
     if (diff[1] == 0.0)
-        i_phi = (!__builtin_signbit(diff[1]) && __builtin_signbit(diff[0]) && !(diff[0] != diff[0])) ? 179 : 0;
+        i_phi8 = (!__builtin_signbit(diff[1]) && __builtin_signbit(diff[0]) && !(diff[0] != diff[0])) ? 179 * 8 : 0;
     else
-        i_phi = bins_passed<256>(bins + kBinsPhi, diff[0] * rcp_nr(diff[1]));
-    return i_phi + i_diff * 360 / 2 + i_half * 360 / 2 * 90;
+        i_phi8 = bins_passed8<256>(bins + kBinsPhi, diff[0] * rcp_nr(diff[1]));
+    return (int)((i_phi8 + i_diff8 * (360 / 2) + i_half8 * (360 / 2 * 90)) >> 3);
 }
 
 // The measured-material term of a lit vertex (the incoming and outgoing directions in the roles

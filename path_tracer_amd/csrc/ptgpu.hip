@@ -1445,14 +1445,11 @@ int pt_brdf_upload(pt_scene* s, int id, const double* table, size_t n) {
     int rc = s->d_brdf[id].ensure(n * sizeof(double));
     if (rc) return rc;
     // The file keeps three planes (red, green, blue; MatusikBRDF.h:68-72).  On the device the three
-    // values of an index are adjacent, so that a lookup touches one or two 64-byte sectors, not three.
+    // values of an index are adjacent, so that a lookup touches one or two 64-byte sectors, not three,
+    // and carry the channel scales of the lookup already.
     std::vector<double> rgb(n);
     const size_t N = n / 3;
-    for (size_t i = 0; i < N; ++i) {
-        rgb[3 * i] = table[i];
-        rgb[3 * i + 1] = table[N + i];
-        rgb[3 * i + 2] = table[2 * N + i];
-    }
+    for (size_t i = 0; i < N; ++i) ptd::brdf_entry(table[i], table[N + i], table[2 * N + i], &rgb[3 * i]);
     HIP_TRY(hipMemcpy(s->d_brdf[id].p, rgb.data(), n * sizeof(double), hipMemcpyHostToDevice));
     s->ds.brdf[id] = (const double*)s->d_brdf[id].p;
     return PT_OK;
