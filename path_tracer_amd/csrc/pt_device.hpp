@@ -120,17 +120,26 @@ PTD_INLINE Rng rng_init(uint64_t seed, uint32_t iteration, uint32_t domain, uint
     return r;
 }
 
-PTD_INLINE int32_t rng_next(Rng& r) {
-    uint32_t result = r.s0 + r.s3;
-    uint32_t t = r.s1 << 9;
-    r.s2 ^= r.s0;
-    r.s3 ^= r.s1;
-    r.s1 ^= r.s2;
-    r.s0 ^= r.s3;
-    r.s2 ^= t;
-    r.s3 = (r.s3 << 11) | (r.s3 >> 21);
-    return (int32_t)(result >> 1);
+// One xoshiro128+ step; returns the 32-bit sum whose upper 31 bits are the draw.  The textbook form
+//   t = s1 << 9; s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = rotl(s3, 11)
+// makes every new word the exclusive-or of three old ones (s1' = s1^s2^s0, s0' = s0^s3^s1,
+// s2' = s2^s0^t), which gfx950 does in one v_bitop3_b32 each (truth table 0x96): 7 VALU
+// instructions a step instead of 8.
+PTD_INLINE uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+PTD_INLINE uint32_t rng_next_sum(Rng& r) {
+    const uint32_t result = r.s0 + r.s3;
+    const uint32_t t = r.s1 << 9;
+    const uint32_t b = r.s3 ^ r.s1;
+    const uint32_t n1 = xor3(r.s1, r.s2, r.s0);
+    const uint32_t n0 = xor3(r.s0, r.s3, r.s1);
+    const uint32_t n2 = xor3(r.s2, r.s0, t);
+    r.s0 = n0;
+    r.s1 = n1;
+    r.s2 = n2;
+    r.s3 = __builtin_amdgcn_alignbit(b, b, 21u);  // rotl(b, 11)
+    return result;
 }
+PTD_INLINE int32_t rng_next(Rng& r) { return (int32_t)(rng_next_sum(r) >> 1); }
 
 // rand() / double(RAND_MAX) with RAND_MAX = 2147483647, i.e. the correctly rounded quotient
 // k / 2147483647.0.  One multiplication by the rounded reciprocal plus one exact-residual
@@ -708,39 +717,36 @@ PTD_INLINE int nearest_hit_shadow(const DScene& S, V3 lc, V3 d, int light, doubl
 // take the exact FP64 test.  The accepted triple is then converted once.  Decisions and results are
 // identical to the plain loop.
 // The float coordinate of a draw comes straight from the generator's 32-bit sum s (the draw is
-// k = s >> 1): the top 23 bits of s become the mantissa of a float in [2, 4), f = 2 + (s >> 9) 2^-22,
-// and f - 3 is exact.  Against the exact coordinate 2 k / (2^31 - 1) - 1 it is low by less than
-// 2^-22 + 2^-30, so the squared length differs by less than 3 * 2 * 2.4e-7 = 1.5e-6, plus 5.4e-7 of
-// float rounding in the three squares and two sums: 2.0e-6, well inside the shell's 1e-5.
-PTD_INLINE uint32_t rng_next_sum(Rng& r) {  // the 32-bit sum whose upper 31 bits are the draw
-    uint32_t result = r.s0 + r.s3;
-    uint32_t t = r.s1 << 9;
-    r.s2 ^= r.s0;
-    r.s3 ^= r.s1;
-    r.s1 ^= r.s2;
-    r.s0 ^= r.s3;
-    r.s2 ^= t;
-    r.s3 = (r.s3 << 11) | (r.s3 >> 21);
-    return result;
-}
-PTD_INLINE float sum_to_coord(uint32_t s) {
-    return __uint_as_float(__builtin_amdgcn_alignbit(0x80u, s, 9u)) - 3.0f;  // 0x40000000 | (s >> 9)
+// k = s >> 1): the loop carries s + 2^31 (mod 2^32) — the constant rides in the generator's own
+// addition (v_add3_u32) — which read as a signed integer is s - 2^31, and one v_cvt_f32_i32 makes it
+// the coordinate scaled by 2^31.  Against the exact coordinate 2 k / (2^31 - 1) - 1 the scaled value
+// (s - 2^31) / 2^31 is off by less than 2^-29 and its rounding to float by at most 2^-25: 3.2e-8, so the
+// squared length differs by less than 3 * 2 * 3.2e-8 = 2e-7, plus 5.4e-7 of float rounding in the three
+// squares and two sums (fewer with fma): 7.4e-7, well inside the shell's 1e-5.
+PTD_INLINE uint32_t rng_next_sum_flipped(Rng& r) {  // rng_next_sum + 2^31 (mod 2^32)
+    const uint32_t a = r.s0, b = r.s3;
+    rng_next_sum(r);
+    uint32_t t;  // written out: the compiler would form a + b and flip the top bit with a second instruction
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "s"(0x80000000u));
+    return t;
 }
 PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
-    uint32_t sz, sy, sx;
+    uint32_t tz, ty, tx;  // flipped sums
     for (;;) {
-        sz = rng_next_sum(dr.rng);
-        sy = rng_next_sum(dr.rng);
-        sx = rng_next_sum(dr.rng);
+        tz = rng_next_sum_flipped(dr.rng);
+        ty = rng_next_sum_flipped(dr.rng);
+        tx = rng_next_sum_flipped(dr.rng);
         dr.count += 3;
-        float fz = sum_to_coord(sz), fy = sum_to_coord(sy), fx = sum_to_coord(sx);
-        float s2 = fx * fx + fy * fy + fz * fz;
-        if (s2 > 1.00001f) continue;
-        if (s2 < 0.99999f) break;
-        const int32_t kz = (int32_t)(sz >> 1), ky = (int32_t)(sy >> 1), kx = (int32_t)(sx >> 1);
+        const float fz = (float)(int32_t)tz, fy = (float)(int32_t)ty, fx = (float)(int32_t)tx;  // coordinates * 2^31
+        const float s2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));                // length^2 * 2^62
+        if (s2 > 1.00001f * 0x1p62f) continue;
+        if (s2 < 0.99999f * 0x1p62f) break;
+        const int32_t kz = (int32_t)((tz ^ 0x80000000u) >> 1), ky = (int32_t)((ty ^ 0x80000000u) >> 1),
+                      kx = (int32_t)((tx ^ 0x80000000u) >> 1);
         V3 e = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
         if (!(dot(e, e) > 1.0)) break;
     }
+    const uint32_t sz = tz ^ 0x80000000u, sy = ty ^ 0x80000000u, sx = tx ^ 0x80000000u;
     const int32_t kz = (int32_t)(sz >> 1), ky = (int32_t)(sy >> 1), kx = (int32_t)(sx >> 1);
     V3 v = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
     if (dot(v, n) < 0.0) v = muls(v, -1.0);
