@@ -154,6 +154,19 @@ PTD_INLINE double k_to_unit(int32_t k) {
     return __builtin_fma(r, c, q0);
 }
 
+// k_to_unit(k) * 2.0 - 1.0, the coordinate of a hemisphere candidate (main.cpp:108), with the doubling
+// folded into the constants: scaling by two commutes with every rounding of k_to_unit, so
+// 2 q0 = kd (2c), the residual kd - (2 q0)(D / 2) is the same number, and fma(r, 2c, 2 q0) is twice
+// the unit value exactly (D / 2 = 1073741823.5 is a double).
+PTD_INLINE double k_to_coord(int32_t k) {
+    const double Dh = 1073741823.5;
+    const double c2 = 0x1.00000002p-30;
+    double kd = (double)k;
+    double q0 = kd * c2;
+    double r = __builtin_fma(-q0, Dh, kd);
+    return __builtin_fma(r, c2, q0) - 1.0;
+}
+
 struct Draws {
     Rng rng;
     int count;
@@ -519,8 +532,34 @@ PTD_INLINE double sel64(lanemask m, double if_set, double if_clear) {
     uint32_t hi = sel32(m, (uint32_t)__double2hiint(if_set), (uint32_t)__double2hiint(if_clear));
     return __hiloint2double((int)hi, (int)lo);
 }
-// (t > 0) && ((t < mint) || (t == mint && i > hit)) && (i != skip), within `valid`.
-// HAS_SKIP false: the caller knows that no body is excluded (skip == -1), body indices being >= 0.
+// mint = t and hit = i in the lanes of `take` (a subset of the active lanes), i being the same for
+// the whole wave: the execution mask is narrowed to `take` around two moves — one 64-bit, one from
+// the scalar register that holds i — where selects would take three v_cndmask and a copy of i into
+// a vector register.  The mask is restored inside the same statement.
+PTD_INLINE void assign_under(lanemask take, double t, int i, double& mint, int& hit) {
+    lanemask saved;
+    asm("s_and_saveexec_b64 %[sv], %[tk]\n\t"
+        "v_mov_b64 %[m], %[t]\n\t"
+        "v_mov_b32 %[h], %[i]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m] "+v"(mint), [h] "+v"(hit), [sv] "=&s"(saved)
+        : [tk] "s"(take), [t] "v"(t), [i] "s"(i)
+        : "scc");
+}
+// Lanes where body i (wave-uniform) replaces the hit so far: (t < mint) || (t == mint && i > hit).
+// Equal distances are rare, so the index compare sits behind a wave-uniform branch.
+PTD_INLINE lanemask wins_mask(double t, double mint, int i, int hit) {
+    lanemask wins = PTD_MASK(t < mint);
+    const lanemask eq = PTD_MASK(t == mint);
+    if (eq != 0) wins |= eq & PTD_MASK(i > hit);
+    return wins;
+}
+// merge_hit for a wave-uniform body index.
+PTD_INLINE void merge_hit_uniform(bool ok, double t, int i, int skip, double eps, int& hit, double& mint) {
+    const lanemask take = PTD_MASK(ok) & PTD_MASK(t > eps) & wins_mask(t, mint, i, hit) & PTD_MASK(i != skip);
+    assign_under(take, t, i, mint, hit);
+}
+// (t > 0) && ((t < mint) || (t == mint && i > hit)) && (i != skip), within `valid`, for a per-lane index.
 template <bool HAS_SKIP>
 PTD_INLINE void merge_masked(lanemask valid, double t, int i, int skip, int& hit, double& mint) {
     lanemask take = valid & PTD_MASK(t > 0.0) & (PTD_MASK(t < mint) | (PTD_MASK(t == mint) & PTD_MASK(i > hit)));
@@ -528,7 +567,6 @@ PTD_INLINE void merge_masked(lanemask valid, double t, int i, int skip, int& hit
     mint = sel64(take, t, mint);
     hit = (int)sel32(take, (uint32_t)i, (uint32_t)hit);
 }
-
 // Two parallel axis-aligned planes, n_lo = c_lo - o_k < n_hi = c_hi - o_k, share the divisor d_k.
 // The quotient that can win the scan is the smallest positive one: for d_k > 0 that of n_lo when
 // n_lo > 0, else that of n_hi; for d_k < 0 that of n_hi when n_hi < 0, else that of n_lo.  Only
@@ -544,8 +582,8 @@ PTD_INLINE void scan_slab(double lo, double hi, double big, int ilo, int ihi, do
     const lanemask pick_lo = (pos & a) | ~(pos | b);
     const lanemask both = (pos & a) | (~pos & b);
     const lanemask valid = PTD_MASK(!(__builtin_fabs(dk) < 0.00001));  // == !((dk > -1e-5) && (dk < 1e-5))
-    const int i = (int)sel32(pick_lo, (uint32_t)ilo, (uint32_t)ihi);
     const double t = sel64(pick_lo, n_lo, n_hi) / dk;
+    const int i = (int)sel32(pick_lo, (uint32_t)ilo, (uint32_t)ihi);
     merge_masked<HAS_SKIP>(valid, t, i, skip, hit, mint);
     lanemask second = both & ~PTD_MASK(__builtin_fabs(ok_) < big);
     if (HAS_SKIP) second |= both & PTD_MASK(i == skip);
@@ -582,9 +620,9 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
                 break;
         }
         const int i = g.pad[0];
-        bool take = ok && (t > eps) && (t <= mint) && (!HAS_SKIP || i != skip);
-        mint = take ? t : mint;
-        hit = take ? i : hit;
+        lanemask take = PTD_MASK(ok) & PTD_MASK(t > eps) & PTD_MASK(t <= mint);
+        if (HAS_SKIP) take &= PTD_MASK(i != skip);
+        assign_under(take, t, i, mint, hit);
     }
     if (S.slab_mask & 1)
         scan_slab<HAS_SKIP>(S.slab_lo[0], S.slab_hi[0], S.slab_big[0], S.slab_ilo[0], S.slab_ihi[0], o.x, d.x, skip, hit, mint);
@@ -677,7 +715,7 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
                 const DGeom g = spheres[2 * k + h];
                 double t;
                 const bool ok = ORIGIN0 ? scan_sphere_exact_origin0(g, d, t) : scan_sphere_exact(g, o, d, t);
-                merge_hit(ok, t, g.pad[0], skip, S.hit_eps, hit, mint);
+                merge_hit_uniform(ok, t, g.pad[0], skip, S.hit_eps, hit, mint);
             }
         }
     }
@@ -743,12 +781,12 @@ PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
         if (s2 < 0.99999f * 0x1p62f) break;
         const int32_t kz = (int32_t)((tz ^ 0x80000000u) >> 1), ky = (int32_t)((ty ^ 0x80000000u) >> 1),
                       kx = (int32_t)((tx ^ 0x80000000u) >> 1);
-        V3 e = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
+        V3 e = mk(k_to_coord(kx), k_to_coord(ky), k_to_coord(kz));
         if (!(dot(e, e) > 1.0)) break;
     }
     const uint32_t sz = tz ^ 0x80000000u, sy = ty ^ 0x80000000u, sx = tx ^ 0x80000000u;
     const int32_t kz = (int32_t)(sz >> 1), ky = (int32_t)(sy >> 1), kx = (int32_t)(sx >> 1);
-    V3 v = mk(k_to_unit(kx) * 2.0 - 1.0, k_to_unit(ky) * 2.0 - 1.0, k_to_unit(kz) * 2.0 - 1.0);
+    V3 v = mk(k_to_coord(kx), k_to_coord(ky), k_to_coord(kz));
     if (dot(v, n) < 0.0) v = muls(v, -1.0);
     return v;
 }
