@@ -317,6 +317,23 @@ struct DScene {
 
 PTD_INLINE V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
 
+// A scene record at a wave-uniform address, read through the constant address space: the scan
+// lists are never written while a kernel runs, and a load from that address space is a scalar
+// load whatever stands between it and the start of the kernel.  (Plain global loads are scalar only
+// while the compiler can show that nothing may have written the memory; a fence or an atomic,
+// even one confined to LDS, ends that, and every later record load becomes a vector load.)
+template <class T>
+PTD_INLINE T load_record(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
+    typedef const __attribute__((address_space(4))) uint32_t* const_dwords;
+    const const_dwords q = (const_dwords)(uintptr_t)p;
+    T out;
+    uint32_t* o = (uint32_t*)&out;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
+    return out;
+}
+
 // Camera::getPoint next_event.cpp:159-161: topleft.add(xd.muls(x)).add(yd.muls(y))
 PTD_INLINE V3 cam_point(const DScene& S, double x, double y) {
     return add(add(ld3(S.cam_tl), muls(ld3(S.cam_xd), x)), muls(ld3(S.cam_yd), y));
@@ -602,7 +619,7 @@ PTD_INLINE void scan_all_planes(const DScene& S, const DGeom* __restrict__ plane
     const int n_planes = S.n_planes;
     const double eps = S.hit_eps;  // slabs exist only in scenes with hit_eps == 0
     for (int k = 0; k < n_planes; ++k) {
-        const DGeom g = planes[k];
+        const DGeom g = load_record(&planes[k]);
         double t;
         bool ok;
         switch (g.shape) {
@@ -702,7 +719,7 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
         const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
         const float e_disc = rf.e_disc, e_b = rf.e_b;
         for (int k = 0; 2 * k < n_spheres; ++k) {
-            const DScreen2 sc = screen[k];
+            const DScreen2 sc = load_record(&screen[k]);
             lanemask m0, m1;
             if (ORIGIN0)
                 sphere_possible2_masks_origin0(fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
@@ -712,7 +729,7 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
             for (int h = 0; h < 2; ++h) {
                 if ((h ? m1 : m0) == 0) continue;
                 PT_PROF(kProfScanExact);
-                const DGeom g = spheres[2 * k + h];
+                const DGeom g = load_record(&spheres[2 * k + h]);
                 double t;
                 const bool ok = ORIGIN0 ? scan_sphere_exact_origin0(g, d, t) : scan_sphere_exact(g, o, d, t);
                 merge_hit_uniform(ok, t, g.pad[0], skip, S.hit_eps, hit, mint);
@@ -1373,7 +1390,8 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
         // The slots are written and read by lanes of one wave, whose LDS instructions execute in
         // program order; the fence pair (wavefront scope, LDS address space only) makes that order part
         // of the program: the stores above may not sink below it nor the loads below rise above it.
-        // Being confined to LDS it leaves the scene record loads of the shadow scans scalar loads.
+        // (The compiler no longer takes plain global loads behind a fence for scalar loads; the
+        // shadow scans below keep theirs because the scan reads its records with load_record.)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         bool lit = false;
