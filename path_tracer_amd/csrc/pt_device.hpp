@@ -579,7 +579,10 @@ PTD_INLINE void merge_hit_uniform(bool ok, double t, int i, int skip, double eps
 // (t > 0) && ((t < mint) || (t == mint && i > hit)) && (i != skip), within `valid`, for a per-lane index.
 template <bool HAS_SKIP>
 PTD_INLINE void merge_masked(lanemask valid, double t, int i, int skip, int& hit, double& mint) {
-    lanemask take = valid & PTD_MASK(t > 0.0) & (PTD_MASK(t < mint) | (PTD_MASK(t == mint) & PTD_MASK(i > hit)));
+    lanemask wins = PTD_MASK(t < mint);
+    const lanemask eq = PTD_MASK(t == mint);
+    if (eq != 0) wins |= eq & PTD_MASK(i > hit);  // equal distances are rare: wave-uniform branch
+    lanemask take = valid & PTD_MASK(t > 0.0) & wins;
     if (HAS_SKIP) take &= PTD_MASK(i != skip);
     mint = sel64(take, t, mint);
     hit = (int)sel32(take, (uint32_t)i, (uint32_t)hit);
@@ -1009,22 +1012,24 @@ struct Records {
     int8_t* bod;  // the fused kernels handle at most 127 bodies
     int stride;
     int tid;
-    PTD_INLINE void put_body(int k, int body) const { bod[k * stride + tid] = (int8_t)body; }
+    // row * stride + t with a 24-bit multiply (full rate; the 32-bit one is quarter rate): rows < 16, stride <= 1024
+    PTD_INLINE int idx(int row, int t) const { return (int)__umul24((unsigned)row, (unsigned)stride) + t; }
+    PTD_INLINE void put_body(int k, int body) const { bod[idx(k, tid)] = (int8_t)body; }
     PTD_INLINE void put(int k, V3 p, int body) const {
-        pts[(k * 3 + 0) * stride + tid] = p.x;
-        pts[(k * 3 + 1) * stride + tid] = p.y;
-        pts[(k * 3 + 2) * stride + tid] = p.z;
-        bod[k * stride + tid] = (int8_t)body;
+        pts[idx(k * 3 + 0, tid)] = p.x;
+        pts[idx(k * 3 + 1, tid)] = p.y;
+        pts[idx(k * 3 + 2, tid)] = p.z;
+        bod[idx(k, tid)] = (int8_t)body;
     }
     PTD_INLINE V3 point(int k) const {
-        return mk(pts[(k * 3 + 0) * stride + tid], pts[(k * 3 + 1) * stride + tid], pts[(k * 3 + 2) * stride + tid]);
+        return mk(pts[idx(k * 3 + 0, tid)], pts[idx(k * 3 + 1, tid)], pts[idx(k * 3 + 2, tid)]);
     }
-    PTD_INLINE int body(int k) const { return bod[k * stride + tid]; }
+    PTD_INLINE int body(int k) const { return bod[idx(k, tid)]; }
     // records of another thread of the block
     PTD_INLINE V3 point_of(int k, int t) const {
-        return mk(pts[(k * 3 + 0) * stride + t], pts[(k * 3 + 1) * stride + t], pts[(k * 3 + 2) * stride + t]);
+        return mk(pts[idx(k * 3 + 0, t)], pts[idx(k * 3 + 1, t)], pts[idx(k * 3 + 2, t)]);
     }
-    PTD_INLINE int body_of(int k, int t) const { return bod[k * stride + t]; }
+    PTD_INLINE int body_of(int k, int t) const { return bod[idx(k, t)]; }
 };
 
 struct PathResult {
