@@ -1146,6 +1146,17 @@ struct SceneUpload {
         for (int li : s->lights)
             for (int k = 0; k < 3; ++k) dead = dead && (s->bodies[li].emission[k] * s->bodies[li].color[k] == 0.0);
         D.nee_emission_only = dead ? 1 : 0;
+        // Absorbing emitters (see trace_path_nee_compact): emission, colour exactly (0, 0, 0).  A lit vertex
+        // on one sets the radiance to its emission whatever lies deeper, provided the deeper radiance is
+        // finite: colours and emissions up to 1e30 keep every product of five levels far from overflow.
+        bool small = dead;
+        for (int i = 0; i < n && small; ++i)
+            for (int k = 0; k < 3; ++k)
+                small = small && std::fabs(s->bodies[i].color[k]) <= 1e30 && std::fabs(s->bodies[i].emission[k]) <= 1e30;
+        for (int i = 0; i < n; ++i) {
+            const pt_body& b = s->bodies[i];
+            mat[i].absorber = small && mat[i].emits && b.color[0] == 0.0 && b.color[1] == 0.0 && b.color[2] == 0.0;
+        }
         D.seed = s->seed;
         for (int k = 0; k < 3; ++k) {
             D.cam_o[k] = s->camera.origin[k];
@@ -1160,8 +1171,8 @@ struct SceneUpload {
         find_slabs();
         scan_lists();
         int rc = sphere_groups();
+        if (rc == PT_OK) classify();  // before the upload: it marks the absorbing emitters in the material records
         if (rc == PT_OK) rc = upload();
-        if (rc == PT_OK) classify();
         return rc;
     }
 };

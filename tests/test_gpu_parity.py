@@ -222,6 +222,47 @@ def test_true_light_centre_flag(port):
     r.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1], ids=["shadow_origin_0", "true_light_centre"])
+def test_absorbing_emitters_in_shadow(port, flags):
+    """The compact next-event kernel scans the vertices deeper than the shallowest lit emitter of colour 0
+    only when that vertex turns out to be in shadow (a second pass of its shadow rounds).  In the
+    reference's room that is one vertex in seven hundred; here diffuse balls around the shadow-ray
+    origin put many of them in shadow, and a chrome and a glass ball beside them add twin vertices."""
+    W, H, seed, n_it = 64, 48, 17, 4
+    d = pt.preset("nee15", W, H, seed=seed)
+    n = d.body_count
+    extra = [(0.0, 0.0, 0.9, 0.45, pt.DIFFUSE), (0.5, 0.9, 0.3, 0.35, pt.DIFFUSE), (-0.6, 0.4, 0.2, 0.3, pt.CHROME),
+             (0.1, -0.7, 0.1, 0.3, pt.GLASS)]
+    bodies = (pt.Body * (n + len(extra)))()
+    for i in range(n):
+        bodies[i] = d.bodies[i]
+    for k, (x, y, z, rad, material) in enumerate(extra):
+        b = pt.Body.from_buffer_copy(d.bodies[6])  # a grey diffuse ball of the room as the template
+        b.shape = pt.SPHERE
+        b.center[0], b.center[1], b.center[2], b.radius = x, y, z, rad
+        b.material = material
+        b.ior, b.reflection = 1.5, 0.1
+        bodies[n + k] = b
+    d.bodies, d.body_count, d._keep = bodies, n + len(extra), bodies
+    d.flags = pt.F_LIGHT_TRUE_CENTER if flags else 0
+    r = pt.Renderer(d)
+    s = oracle_scene(port, r, W, H, seed, flags=flags)
+    want, _ = port.render(s, MODE_PIXEL, 0, n_it)
+    assert same_bits(r.render(0, n_it), want)
+    # the case is really there: paths whose shallowest emitter vertex is in shadow and has an emitter below it
+    rng = np.random.default_rng(3)
+    m = 20000
+    it_idx = np.stack([rng.integers(0, 64, m), rng.integers(0, W * H, m)], axis=1).astype(np.int32)
+    g = r.trace_paths(it_idx, rng.uniform(0, 1, size=(m, 2)))
+    emit = [i for i in range(d.body_count) if max(bodies[i].emission) != 0.0]
+    cases = 0
+    for bod, k, vis in zip(g["bodies"], g["nrec"], g["visible"]):
+        on = [j for j in range(k) if bod[j] in emit]
+        cases += len(on) >= 2 and not (vis >> on[0]) & 1
+    assert cases > 10, cases
+    r.close()
+
+
 def test_measured_brdf_lookup_and_render(port):
     z = np.load(os.path.join(GOLDEN, "brdf.npz"))
     d = pt.preset("nee15_measured", 40, 30, seed=6)
