@@ -494,12 +494,52 @@ PTD_INLINE RayF make_rayf(V3 o, V3 d, float c1max, float r2max) {
     return r;
 }
 
+// Packed FP32 operations with one operand broadcast from a single float: the packed instructions can
+// read the low half of a register pair for both results (op_sel_hi), so the ray's components need
+// no second copy in the high halves (the compiler's own form spends a v_mov per component and scan).
+// `lo` carries the value in .x; .y is never read.
+PTD_INLINE f32x2 lo_half(float v) {
+    f32x2 t;
+    t.x = v;
+    asm("" : "+v"(t));  // .y stays undefined: no instruction is spent on it
+    return t;
+}
+PTD_INLINE f32x2 pk_bcast_sub(f32x2 lo, f32x2 b) {  // lo.x - b
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(lo), "s"(b));
+    return r;
+}
+PTD_INLINE f32x2 pk_mul_bcast(f32x2 a, f32x2 lo) {  // a * lo.x
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(lo));
+    return r;
+}
+PTD_INLINE f32x2 pk_fma_bcast(f32x2 a, f32x2 lo, f32x2 c) {  // a * lo.x + c
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(lo), "v"(c));
+    return r;
+}
+PTD_INLINE f32x2 pk_smul_bcast(f32x2 s_ab, f32x2 lo) {  // s_ab (a scalar register pair) * lo.x
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(s_ab), "v"(lo));
+    return r;
+}
+PTD_INLINE f32x2 pk_sfma_bcast(f32x2 s_ab, f32x2 lo, f32x2 c) {  // s_ab * lo.x + c
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "s"(s_ab), "v"(lo), "v"(c));
+    return r;
+}
+// The ray of the screen with its components in the low halves of register pairs.
+struct RayF2 {
+    f32x2 ox, oy, oz, dx, dy, dz;
+};
+
 // The screen for two bodies at once (packed FP32), as wave masks: m0 / m1 = lanes that might hit
-// body 0 / 1 (NaN compares as "might").
-PTD_INLINE void sphere_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
-                                       float e_b, const DScreen2& sc, lanemask& m0, lanemask& m1) {
-    f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
-    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
+// body 0 / 1 (NaN compares as "might").  `sc` must sit in scalar registers (load_record).
+PTD_INLINE void sphere_possible2_masks(const RayF2& r, float e_disc, float e_b, const DScreen2& sc, lanemask& m0,
+                                       lanemask& m1) {
+    f32x2 Dx = pk_bcast_sub(r.ox, sc.cx), Dy = pk_bcast_sub(r.oy, sc.cy), Dz = pk_bcast_sub(r.oz, sc.cz);
+    f32x2 bf = pk_fma_bcast(Dz, r.dz, pk_fma_bcast(Dy, r.dy, pk_mul_bcast(Dx, r.dx)));
     f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
     f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
     m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
@@ -668,11 +708,23 @@ PTD_INLINE bool scan_sphere_exact_origin0(const DGeom& g, V3 d, double& t) {
     }
     return ok;
 }
+// The same screen in the compiler's own form (ray components as plain floats): the grouped scan of
+// the large-scene pipeline uses it.
+PTD_INLINE void sphere_possible2_masks(float ox, float oy, float oz, float dx, float dy, float dz, float e_disc,
+                                       float e_b, const DScreen2& sc, lanemask& m0, lanemask& m1) {
+    f32x2 Dx = ox - sc.cx, Dy = oy - sc.cy, Dz = oz - sc.cz;
+    f32x2 bf = __builtin_elementwise_fma(Dz, (f32x2)(dz), __builtin_elementwise_fma(Dy, (f32x2)(dy), Dx * dx));
+    f32x2 cf = __builtin_elementwise_fma(Dz, Dz, __builtin_elementwise_fma(Dy, Dy, Dx * Dx)) - sc.r2;
+    f32x2 discf = __builtin_elementwise_fma(bf, bf, -cf);
+    m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
+    m1 = PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b));
+}
+
 // The sphere screen from the origin (0,0,0): the record holds the centre and, in place of r^2,
 // the float c-term |c|^2 - r^2.  Same error bounds as sphere_possible2_masks.
-PTD_INLINE void sphere_possible2_masks_origin0(float dx, float dy, float dz, float e_disc, float e_b, const DScreen2& sc,
-                                               lanemask& m0, lanemask& m1) {
-    f32x2 bf = -__builtin_elementwise_fma(sc.cz, (f32x2)(dz), __builtin_elementwise_fma(sc.cy, (f32x2)(dy), sc.cx * dx));
+PTD_INLINE void sphere_possible2_masks_origin0(const RayF2& r, float e_disc, float e_b, const DScreen2& sc, lanemask& m0,
+                                               lanemask& m1) {
+    f32x2 bf = -pk_sfma_bcast(sc.cz, r.dz, pk_sfma_bcast(sc.cy, r.dy, pk_smul_bcast(sc.cx, r.dx)));
     f32x2 discf = __builtin_elementwise_fma(bf, bf, -sc.r2);
     m0 = PTD_MASK(!(discf.x < -e_disc)) & PTD_MASK(!(bf.x > e_b));
     m1 = PTD_MASK(!(discf.y < -e_disc)) & PTD_MASK(!(bf.y > e_b));
@@ -722,15 +774,17 @@ PTD_INLINE int nearest_hit_lists(const DScene& S, const DGeom* __restrict__ plan
     if (n_spheres > 0) {
         PT_PROF(kProfScanScreen);
         const RayF rf = make_rayf(ORIGIN0 ? mk(0.0, 0.0, 0.0) : o, d, S.sphere_c1max, S.sphere_r2max);
-        const float fox = rf.ox, foy = rf.oy, foz = rf.oz, fdx = rf.dx, fdy = rf.dy, fdz = rf.dz;
+        RayF2 r2;
+        r2.ox = lo_half(rf.ox), r2.oy = lo_half(rf.oy), r2.oz = lo_half(rf.oz);
+        r2.dx = lo_half(rf.dx), r2.dy = lo_half(rf.dy), r2.dz = lo_half(rf.dz);
         const float e_disc = rf.e_disc, e_b = rf.e_b;
         for (int k = 0; 2 * k < n_spheres; ++k) {
             const DScreen2 sc = load_record(&screen[k]);
             lanemask m0, m1;
             if (ORIGIN0)
-                sphere_possible2_masks_origin0(fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
+                sphere_possible2_masks_origin0(r2, e_disc, e_b, sc, m0, m1);
             else
-                sphere_possible2_masks(fox, foy, foz, fdx, fdy, fdz, e_disc, e_b, sc, m0, m1);
+                sphere_possible2_masks(r2, e_disc, e_b, sc, m0, m1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if ((h ? m1 : m0) == 0) continue;
