@@ -1390,6 +1390,13 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
     return R;
 }
 
+// The double `v` of lane `src` (0..63) of the wave, through ds_bpermute: no LDS is allocated.
+PTD_INLINE double lane_read(double v, int src) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // NEE sample for scenes whose direct term is dead for every light and every material
 // (DScene::nee_emission_only: emission*colour of each light is exactly zero, no measured material,
 // every glass ior >= 1, finite moderate geometry and colours).  The pixel value is then the recurrence
@@ -1406,6 +1413,7 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
                                      uint16_t* __restrict__ wave_slots) {
     int n = 0, need = 0, light = 0;
     int first_abs = -1;  // the shallowest vertex on an absorbing emitter
+    V3 p_last = mk(0.0, 0.0, 0.0);  // position of vertex kMaxDepth - 1
     unsigned twin = 0;  // bit k: chrome or glass vertex k coincides with the vertex before it (the camera-plane point for k = 0)
     if (valid) {
         V3 o = ld3(S.cam_o);
@@ -1418,7 +1426,12 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
             if (hit < 0) break;
             const DMat& m = S.mat[hit];
             V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);  // o = point on return
-            rec.put(n, point, hit);
+            if (n < kMaxDepth - 1) {
+                rec.put(n, point, hit);
+            } else {  // the records hold kMaxDepth - 1 positions: the deepest vertex keeps its own
+                rec.put_body(n, hit);
+                p_last = point;
+            }
             const bool tw = (m.material != kDiffuse) & same_point(point, prev);
             twin |= (tw ? 1u : 0u) << n;
             if (m.emits | tw) need = n + 1;  // a lit twin vertex turns the pixel into NaN: its visibility matters
@@ -1482,14 +1495,19 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         bool lit = false;
+        // every lane reads a slot (those past the count a stale one) and fetches the owner's deepest
+        // position through the lane crossbar, which needs owner and taker both active
+        const unsigned slot = wave_slots[lane];
+        const V3 p_deep = mk(lane_read(p_last.x, (int)(slot & 63u)), lane_read(p_last.y, (int)(slot & 63u)),
+                             lane_read(p_last.z, (int)(slot & 63u)));
         if (base + lane < total) {
-            const unsigned slot = wave_slots[lane];
             const int g = (int)((slot >> 6) & 7u), lt = (int)(slot >> 9);
             const int owner = wave_tid0 | (int)(slot & 63u);
             V3 P, bd, lc;
             {
                 PT_PROF(kProfNeePrep);
-                P = rec.point_of(g, owner);
+                P = rec.point_of(g < kMaxDepth - 1 ? g : 0, owner);
+                if (g == kMaxDepth - 1) P = p_deep;
                 lc = light_origin(S, lt);
                 bd = normalize(sub(P, lc));  // next_event.cpp:405-407
             }

@@ -167,11 +167,13 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
 // shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
-    __shared__ double s_pts[EST == kEstPT ? 1 : kMaxDepth * 3 * kBlock];  // path tracing keeps no vertex positions
+    // path tracing keeps no vertex positions; the compact next-event form keeps the deepest vertex's in
+    // registers (see trace_path_nee_compact), which lets a sixth block share the CU's LDS
+    __shared__ double s_pts[EST == kEstPT ? 1 : (COMPACT ? kMaxDepth - 1 : kMaxDepth) * 3 * kBlock];
     __shared__ int8_t s_bod[kMaxDepth * kBlock];
     __shared__ uint16_t s_slots[COMPACT ? kBlock : 1];
     const int tid = threadIdx.x;
