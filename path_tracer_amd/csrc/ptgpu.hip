@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 // (5 x 32 KB) just fit the 160 KiB of a CU and the register file allows 96 VGPRs per lane; the
 // estimator is bound by VALU issue, and the fifth wave buys ~8 %.
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
-// shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.
+// shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.  That form
+// keeps four positions per path in LDS (26 368 B per block) and fits 80 VGPRs: six blocks per CU.
 template <int EST, bool MEASURED, bool COMPACT = false>
 __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
@@ -541,10 +542,16 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     P.tiles_y = (s->height + th - 1) / th;
     int total = P.tiles_x * P.tiles_y;
     P.owned_tiles = total > rank ? (total - rank + world - 1) / world : 0;
-    // batch: about 2^24 paths per launch, at most 128 iterations (a rank that owns an eighth of a
-    // 1024x768 frame then still launches 1.3e7 paths at a time)
+    // batch: about 2^27 paths per launch, at most 128 iterations (a rank that owns an eighth of a
+    // 1024x768 frame then still launches 1.3e7 paths at a time; the samples of a batch take 3.2 GB at
+    // most).  The frame layout and the accumulation of a batch run beside the estimator of its
+    // neighbours on the little that kernel leaves free of a CU (six blocks of 80 registers fill it), so
+    // their share per path must be small: at 3840x2160 a batch of two iterations (2^24 paths) made the
+    // accumulator traffic per path as large as the samples' and the estimator waited for it
+    // (7.0e9 paths/s; 2^25: 7.8e9, 2^26: 8.2e9, 2^27: 8.5e9).  PTGPU_BATCH_LOG2 overrides (development).
     size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
-    size_t b = ((size_t)1 << 24) / per_it;
+    const char* lg = getenv("PTGPU_BATCH_LOG2");
+    size_t b = ((size_t)1 << (lg ? atoi(lg) : 27)) / per_it;
     s->batch = (int)std::min<size_t>(128, std::max<size_t>(1, b));
     // the wavefront pipeline keeps 364 B of state per path in HBM: batches of 2^26 paths (24 GB, with
     // the samples 28 GB of the 288) — the more paths, the more coherent the waves the ray sort
