@@ -167,8 +167,9 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
 // shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.  That form
 // keeps four positions per path in LDS (26 368 B per block) and fits 80 VGPRs: six blocks per CU.
+// The path-tracing kernel keeps no positions and fits 64 VGPRs: eight.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 7 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
