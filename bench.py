@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--proxy-world", type=int, default=0,
+                    help="single-GPU proxy of strong scaling: render only rank 0's tiles of a world of this many ranks "
+                         "(full iteration count, no exchange) and report that rank's time")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.scene:
@@ -216,9 +219,15 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     exchange = ptdist.Exchange(r, world, accum.device) if args.exchange == "gather" else None
 
+    proxy = args.proxy_world if world == 1 else 0
+
     def step():
         accum.zero_()
-        ptdist.render_distributed(r, 0, IT, accum, rank, world, stream, exchange=exchange)
+        if proxy:
+            r.set_partition(0, proxy, ptdist.TILE_W, ptdist.TILE_H)
+            r.render_device(0, IT, accum.data_ptr(), stream)
+        else:
+            ptdist.render_distributed(r, 0, IT, accum, rank, world, stream, exchange=exchange)
 
     def fence():
         torch.cuda.synchronize()
@@ -245,7 +254,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    paths = float(W) * H * IT * args.steps
+    paths = traced if proxy else float(W) * H * IT * args.steps
     checksum = float(accum.sum().item()) / (W * H * 3 * IT)
     if rank == 0:
         out = {
@@ -273,6 +282,12 @@ def main():
                 "mean_radiance": checksum,
             },
         }
+        if proxy:
+            # what one rank of `proxy` ranks does on its GPU, measured alone: value is that rank's path rate,
+            # rank_seconds its time for the whole workload's share; T(1) / (N T(N)) is the efficiency
+            out["proxy"] = {"world": proxy, "rank": 0, "rank_seconds_per_step": elapsed / args.steps,
+                            "rank_paths_per_step": traced / args.steps, "exchange": "not run"}
+            out["config"]["partition"] = f"rank 0 of {proxy} (interleaved 32x8 tiles), alone on one GPU, no exchange"
         if launches > 0:
             paths_per_launch = traced / launches  # rank 0's own launches: a per-GPU figure when N > 1
             avg_ms = kernel_ms / launches
@@ -339,7 +354,7 @@ def main():
                 out["roofline"]["frac_kind"] = "algorithmic-equivalent (brute-force body tests at FP64 cost); executed.frac_of_peak is what the FP64 units did"
             if world > 1:
                 out["roofline"]["note"] += "; rank 0's kernel launches, per-GPU rate"
-            if world == 1 and as_configured and args.config == "C2":
+            if world == 1 and not proxy and as_configured and args.config == "C2":
                 # the same scene with the direct term live (light colour 1): every shadow scan and fake-BRDF
                 # bounce is executed, nothing is proven dead — the rate of the kernel family without the
                 # compact next-event form, measured on a short run beside the headline
@@ -357,7 +372,7 @@ def main():
                     "scene": "nee15_lit", "iterations": lit_it, "paths_per_s": lit_rate,
                     "algorithmic_frac": lit_rate * flop_per_path / 1e12 / FP64_VALU_PEAK_TFLOPS,
                 }
-            if world == 1 and not args.no_cpu:
+            if world == 1 and not proxy and not args.no_cpu:
                 cb = cpu_baseline(desc, scene, W, H, [t for t in tables] if tables else None, args.cpu_seconds)
                 out["cpu_baseline"] = cb
                 out["config"]["gpu_over_cpu"] = out["value"] / cb["value"]
