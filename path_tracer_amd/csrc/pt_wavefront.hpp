@@ -414,7 +414,7 @@ __device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, Sl
         if (S.flags & 4u) {
             x = (double)c / (double)Wd;  // light_tracing.cpp:787
         } else {
-            x = xs[((size_t)b * H + r) * CK + c / xstride];
+            x = xs[((size_t)b * CK + c / xstride) * H + r];
             for (int i = c % xstride; i > 0; --i) x += xstep;
         }
         double y = ys[(size_t)b * H + r];

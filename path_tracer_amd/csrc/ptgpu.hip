@@ -1,7 +1,7 @@
 // ptgpu — kernels and C ABI (see include/ptgpu.h).  gfx950 only.
 //
 // Render pipeline for one batch of B iterations:
-//   k_frame_layout : per iteration, the jitter tables of Renderer::iterate (main.cpp:352-357):
+//   k_layout_*     : per iteration, the jitter tables of Renderer::iterate (main.cpp:352-357):
 //                    y per row, x at every 8th pixel of a row (running sums, exactly as the
 //                    reference's loops accumulate them; k_trace continues the sum from the nearest
 //                    checkpoint), row lengths and the running-index row starts.
@@ -80,71 +80,80 @@ PTD_INLINE int slot_of(const Partition& P, int q, int tid, int W, int H, int* ro
     return py * W + px;
 }
 
-// ---- k_frame_layout ----------------------------------------------------------------------
-// One block per iteration.  Each thread owns a contiguous chunk of rows: it runs their x chains
-// (x0 = u/W, then x += xstep while x < 0.99999L, main.cpp:355-357), thread 0 also runs the y
-// chain (main.cpp:352-354); a block scan turns row lengths into running-index row starts.
+// ---- frame layout -------------------------------------------------------------------------
+// The jitter tables of a batch of iterations, in three small kernels on one stream.  Their blocks
+// are one wave (y and x chains) or four (prefix sums) of few registers and next to no LDS, so that
+// they find room on a CU beside the estimator blocks of the neighbouring batch, which leave one
+// wave slot per SIMD free.
+//   k_layout_y    : thread per iteration: the y chain (y0 = u/H, then y += ystep while y < 0.99999L,
+//                   main.cpp:352-354); the number of rows it yields goes to nrows[b].
+//   k_layout_rows : thread per (iteration, row): the row's x chain (x0 = u/W, then x += xstep while
+//                   x < 0.99999L, main.cpp:355-357), stored at every 8th column, checkpoint-major
+//                   (xs[b][c/8][r]: the 64 rows of a wave store 512 contiguous bytes); the row length
+//                   goes to row_start[b][r+1].
+//   k_layout_scan : block per iteration: row lengths -> running-index row starts, npix[b].
 // xstep/ystep are the doubles the reference initialises from 1.0L/(double)W and 1.0L/(double)H.
 // GRID (PT_F_PIXEL_GRID, Renderer::ray_iterate light_tracing.cpp:785-790): no jitter, every row full,
 // y of row r = (double)r / (double)H; k_trace forms x = (double)c / (double)W itself.
-__global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int H, int first_it, double xstep,
-                                                       double ystep, double* __restrict__ xs, double* __restrict__ ys,
-                                                       int32_t* __restrict__ row_start, int32_t* __restrict__ npix, int grid) {
-    __shared__ int s_part[1024];
-    __shared__ int s_nrows;
-    const int b = blockIdx.x;
+constexpr int kLayoutWave = 64;
+constexpr int kScanBlock = 256;
+
+__global__ void __launch_bounds__(kLayoutWave) k_layout_y(uint64_t seed, int H, int first_it, int B, double ystep,
+                                                          double* __restrict__ ys, int32_t* __restrict__ nrows, int grid) {
+    const int b = blockIdx.x * kLayoutWave + threadIdx.x;
+    if (b >= B) return;
+    double* ys_b = ys + (size_t)b * H;
     if (grid) {
-        for (int r = threadIdx.x; r <= H; r += blockDim.x) {
-            if (r < H) ys[(size_t)b * H + r] = (double)r / (double)H;
-            row_start[(size_t)b * (H + 1) + r] = r * W;
-        }
-        if (threadIdx.x == 0) npix[b] = W * H;
+        for (int r = 0; r < H; ++r) ys_b[r] = (double)r / (double)H;
+        nrows[b] = H;
         return;
     }
-    const uint32_t it = (uint32_t)(first_it + b);
-    const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
-    const int chunk = (H + nthr - 1) / nthr;
-    const int r0 = tid * chunk;
-    const int r1 = min(H, r0 + chunk);
-    const int CK = (W + kXStride - 1) / kXStride;
-    double* xs_b = xs + (size_t)b * H * CK;
-    double* ys_b = ys + (size_t)b * H;
-    int32_t* rs_b = row_start + (size_t)b * (H + 1);
+    Rng j = rng_init(seed, (uint32_t)(first_it + b), kDomFrame, 0);
+    double y = k_to_unit(rng_next(j)) / (double)H;
+    int r = 0;
+    while (y < 0.99999 && r < H) {
+        ys_b[r] = y;
+        r++;
+        y += ystep;
+    }
+    nrows[b] = r;
+}
 
-    if (tid == 0) {
-        Rng j = rng_init(seed, it, kDomFrame, 0);
-        double y = k_to_unit(rng_next(j)) / (double)H;
-        int r = 0;
-        while (y < 0.99999 && r < H) {
-            ys_b[r] = y;
-            r++;
-            y += ystep;
+__global__ void __launch_bounds__(kLayoutWave) k_layout_rows(uint64_t seed, int W, int H, int first_it, double xstep,
+                                                             double* __restrict__ xs, const int32_t* __restrict__ nrows,
+                                                             int32_t* __restrict__ row_start, int grid) {
+    const int r = blockIdx.x * kLayoutWave + threadIdx.x;
+    const int b = blockIdx.y;
+    if (r >= H) return;
+    int len = 0;
+    if (grid) {
+        len = W;
+    } else if (r < nrows[b]) {
+        const int CK = (W + kXStride - 1) / kXStride;
+        double* col = xs + (size_t)b * CK * H + r;
+        Rng j = rng_init(seed, (uint32_t)(first_it + b), kDomRow, (uint32_t)r);
+        double x = k_to_unit(rng_next(j)) / (double)W;
+        while (x < 0.99999 && len < W) {
+            if ((len & (kXStride - 1)) == 0) col[(size_t)(len / kXStride) * H] = x;
+            len++;
+            x += xstep;
         }
-        s_nrows = r;
     }
-    __syncthreads();
-    const int nrows = s_nrows;
+    row_start[(size_t)b * (H + 1) + r + 1] = len;  // the row length, until k_layout_scan has run
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_layout_scan(int H, int32_t* __restrict__ row_start, int32_t* __restrict__ npix) {
+    __shared__ int s_part[kScanBlock];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t* rs_b = row_start + (size_t)b * (H + 1);
+    const int chunk = (H + kScanBlock - 1) / kScanBlock;
+    const int r0 = min(H, tid * chunk), r1 = min(H, r0 + chunk);
     int local = 0;
-    for (int r = r0; r < r1; ++r) {
-        int len = 0;
-        if (r < nrows) {
-            Rng j = rng_init(seed, it, kDomRow, (uint32_t)r);
-            double x = k_to_unit(rng_next(j)) / (double)W;
-            double* row = xs_b + (size_t)r * CK;
-            while (x < 0.99999 && len < W) {
-                if ((len & (kXStride - 1)) == 0) row[len / kXStride] = x;
-                len++;
-                x += xstep;
-            }
-        }
-        rs_b[r + 1] = len;  // temporarily the row length
-        local += len;
-    }
+    for (int r = r0; r < r1; ++r) local += rs_b[r + 1];
     s_part[tid] = local;
     __syncthreads();
     // inclusive Hillis-Steele scan over the per-thread totals
-    for (int off = 1; off < nthr; off <<= 1) {
+    for (int off = 1; off < kScanBlock; off <<= 1) {
         int v = (tid >= off) ? s_part[tid - off] : 0;
         __syncthreads();
         s_part[tid] += v;
@@ -152,12 +161,21 @@ __global__ void __launch_bounds__(1024) k_frame_layout(uint64_t seed, int W, int
     }
     int run = s_part[tid] - local;  // exclusive prefix
     for (int r = r0; r < r1; ++r) {
-        int len = rs_b[r + 1];
-        if (r == 0) rs_b[0] = 0;
-        run += len;
+        run += rs_b[r + 1];
         rs_b[r + 1] = run;
     }
-    if (tid == nthr - 1) npix[b] = s_part[tid];
+    if (tid == 0) rs_b[0] = 0;
+    if (tid == kScanBlock - 1) npix[b] = s_part[tid];
+}
+
+// Queues the three layout kernels of iterations [first_it, first_it + B) on `st`.
+void launch_frame_layout(hipStream_t st, uint64_t seed, int W, int H, int first_it, int B, double xstep, double ystep, double* xs,
+                         double* ys, int32_t* row_start, int32_t* npix, int grid) {
+    hipLaunchKernelGGL(k_layout_y, dim3((B + kLayoutWave - 1) / kLayoutWave), dim3(kLayoutWave), 0, st, seed, H, first_it, B, ystep,
+                       ys, npix, grid);
+    hipLaunchKernelGGL(k_layout_rows, dim3((H + kLayoutWave - 1) / kLayoutWave, B), dim3(kLayoutWave), 0, st, seed, W, H, first_it,
+                       xstep, xs, npix, row_start, grid);
+    hipLaunchKernelGGL(k_layout_scan, dim3(B), dim3(kScanBlock), 0, st, H, row_start, npix);
 }
 
 // ---- k_trace -----------------------------------------------------------------------------
@@ -211,7 +229,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
         if (S.flags & 4u) {
             x = (double)c / (double)W;  // light_tracing.cpp:787
         } else {
-            x = xs[((size_t)b * H + r) * CK + c / kXStride];
+            x = xs[((size_t)b * CK + c / kXStride) * H + r];
             for (int i = c & (kXStride - 1); i > 0; --i) x += xstep;
         }
         y = ys[(size_t)b * H + r];
@@ -507,7 +525,8 @@ struct pt_scene {
     hipEvent_t ev_entry = nullptr, ev_layout[2] = {nullptr, nullptr}, ev_trace[2] = {nullptr, nullptr},
                ev_acc[2] = {nullptr, nullptr};
     double xstep = 0, ystep = 0;
-    int batch = 1;
+    int batch = 1;        // iterations per fused batch, at most
+    int batch_alloc = 0;  // iterations per batch the fused buffers are sized for (grows with the calls)
     std::vector<hipEvent_t> ev;  // start/stop pairs of the estimator launches of the last render
     size_t ev_used = 0;
     double last_paths = 0;
@@ -529,6 +548,8 @@ struct pt_scene {
 
 namespace {
 
+constexpr int kMaxBatchIterations = 1024;
+
 int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     if (world < 1 || rank < 0 || rank >= world) return fail(PT_ERR_INVALID, "partition: rank/world out of range");
     if (tw < 1 || th < 1 || tw * th != kBlock) return fail(PT_ERR_INVALID, "partition: tile_w*tile_h must be 256");
@@ -543,17 +564,21 @@ int setup_partition(pt_scene* s, int rank, int world, int tw, int th) {
     P.tiles_y = (s->height + th - 1) / th;
     int total = P.tiles_x * P.tiles_y;
     P.owned_tiles = total > rank ? (total - rank + world - 1) / world : 0;
-    // batch: about 2^27 paths per launch, at most 128 iterations (a rank that owns an eighth of a
-    // 1024x768 frame then still launches 1.3e7 paths at a time; the samples of a batch take 3.2 GB at
-    // most).  The frame layout and the accumulation of a batch run beside the estimator of its
-    // neighbours on the little that kernel leaves free of a CU (six blocks of 80 registers fill it), so
-    // their share per path must be small: at 3840x2160 a batch of two iterations (2^24 paths) made the
-    // accumulator traffic per path as large as the samples' and the estimator waited for it
-    // (7.0e9 paths/s; 2^25: 7.8e9, 2^26: 8.2e9, 2^27: 8.5e9).  PTGPU_BATCH_LOG2 overrides (development).
+    // batch: about 2^27 paths per launch, whatever share of the frame the partition owns (a rank that
+    // owns an eighth of a 1024x768 frame takes 1 024 iterations at a time: with the launches as long as a
+    // single GPU's, the ends of launches, where the chip runs half empty, weigh no more than there).
+    // The frame layout and the accumulation of a batch run beside the estimator of its neighbours on
+    // the little that kernel leaves free of a CU (six blocks of 80 registers fill it), so their share
+    // per path must be small: at 3840x2160 a batch of two iterations (2^24 paths) made the accumulator
+    // traffic per path as large as the samples' and the estimator waited for it (7.0e9 paths/s; 2^25:
+    // 7.8e9, 2^26: 8.2e9, 2^27: 8.5e9).  The samples of a batch take 3.2 GB at most, its tables 0.8 GB.
+    // PTGPU_BATCH_LOG2 overrides (development).
     size_t per_it = (size_t)std::max(1, P.owned_tiles) * kBlock;
     const char* lg = getenv("PTGPU_BATCH_LOG2");
-    size_t b = ((size_t)1 << (lg ? atoi(lg) : 27)) / per_it;
-    s->batch = (int)std::min<size_t>(128, std::max<size_t>(1, b));
+    const int log2_paths = lg ? std::min(30, std::max(16, atoi(lg))) : 27;
+    size_t b = ((size_t)1 << log2_paths) / per_it;
+    s->batch = (int)std::min<size_t>(kMaxBatchIterations, std::max<size_t>(1, b));
+    s->batch_alloc = 0;  // sized again by the next call
     // the wavefront pipeline keeps 364 B of state per path in HBM: batches of 2^26 paths (24 GB, with
     // the samples 28 GB of the 288) — the more paths, the more coherent the waves the ray sort
     // forms (2^24: 6.85e8, 2^25: 7.09e8, 2^26: 7.19e8, 2^27: 7.28e8 paths/s on the 10 000-body scene)
@@ -571,7 +596,7 @@ bool uses_wavefront(const pt_scene* s) {
 }
 
 int ensure_render_buffers(pt_scene* s) {
-    const size_t W = s->width, H = s->height, B = (size_t)(uses_wavefront(s) ? std::max(1, s->wf_batch_alloc) : s->batch);
+    const size_t W = s->width, H = s->height, B = (size_t)std::max(1, uses_wavefront(s) ? s->wf_batch_alloc : s->batch_alloc);
     int rc;
     size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     for (int k = 0; k < 2; ++k) {
@@ -582,6 +607,9 @@ int ensure_render_buffers(pt_scene* s) {
         if ((rc = s->d_samples[k].ensure(B * 3 * J * sizeof(double)))) return rc;
     }
     if (!s->st_layout) {
+        // Default priority on purpose: with side streams of another priority a render on a stream of the
+        // caller's followed by an RCCL collective in the same process never completed (the process has four
+        // hardware queues), and the layout kernels find their room beside the estimator without it.
         HIP_TRY(hipStreamCreateWithFlags(&s->st_layout, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&s->st_accum, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_entry, hipEventDisableTiming));
@@ -1192,7 +1220,8 @@ int upload_scene(pt_scene* s) { return SceneUpload(s).run(); }
 int ensure_wavefront_buffers(pt_scene* s) {
     const size_t J = (size_t)std::max(1, s->part.owned_tiles) * kBlock;
     const size_t cap = J * (size_t)s->wf_batch_alloc;
-    if (s->wf.cap == cap && s->d_wf.p) return PT_OK;
+    if (s->wf.cap == cap && s->d_wf.p && s->d_wf_sort.p && s->wf_counts_host) return PT_OK;
+    s->wf.cap = 0;  // not usable until every allocation and query below has succeeded
     // per path: a ray record, kMaxDepth vertex records; doubles: xy 2; 32-bit words: rng 4, nrec 1, light 1,
     // need 1, queue 11, sorted 1, keys 1 + 5 = 25; plus the 16 queue counters
     size_t bytes = cap * (sizeof(ptw::RayRec) + kMaxDepth * sizeof(ptw::VertexRec) + 2 * sizeof(double) + 25 * sizeof(int32_t)) +
@@ -1214,7 +1243,6 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.sorted = W.qcount + 16;
     W.keys = (uint32_t*)(W.sorted + cap);
     W.skeys = W.keys + cap;
-    W.cap = cap;
     // the ray sort (rocprim radix sort of 16-bit keys with the path ids as values)
     size_t tmp = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, W.keys, W.keys, W.queue, W.sorted, cap, 0u, ptw::kSortKeyBits, (hipStream_t)0));
@@ -1225,6 +1253,7 @@ int ensure_wavefront_buffers(pt_scene* s) {
         for (int k = 0; k < 16; ++k) s->wf_counts_host[k] = -1;
     }
     s->wf_counts_cap = 0;  // no counts for this capacity yet
+    W.cap = cap;
     return PT_OK;
 }
 
@@ -1255,6 +1284,8 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         const double frac = (double)before / (double)s->wf_counts_cap;
         return (int)std::min<double>((double)cap, frac * 1.03 * (double)cap + 4096.0);
     };
+    // A sort the library refuses (it reports bad arguments or too little temporary storage through its
+    // return value only) leaves n_sorted at 0: the scan then reads the queue in its own order, same results.
     auto sorted_list = [&](int mode, int qi, int gi, int* n_sorted) -> const int32_t* {
         *n_sorted = 0;
         if (!s->wf_sort) return W.sorted;
@@ -1263,8 +1294,16 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         uint32_t* keys_out = (uint32_t*)s->d_wf_sort.p;
         void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
         size_t tmp_bytes = s->wf_sort_tmp_bytes;
-        (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)n, 0u,
-                                        mode == kShadow ? kShadowKeyBits : kSortKeyBits, st);  // errors surface at hipGetLastError below
+        const unsigned bits = mode == kShadow ? kShadowKeyBits : kSortKeyBits;
+        size_t need = 0;  // the library picks its algorithm by size: ask what this call needs
+        if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)n, 0u, bits,
+                                      st) != hipSuccess || need > tmp_bytes)
+            return W.sorted;
+        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, W.queue + (size_t)qi * W.cap, W.sorted, (size_t)n, 0u, bits,
+                                      st) != hipSuccess) {
+            (void)hipGetLastError();
+            return W.sorted;
+        }
         *n_sorted = n;
         return W.sorted;
     };
@@ -1351,10 +1390,6 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (e != hipSuccess) {
         delete s;
         return fail(PT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    }
-    if (int rcs = scratch_address(s->device, &s->scratch_ptr)) {
-        delete s;
-        return rcs;
     }
     s->width = desc->width;
     s->height = desc->height;
@@ -1559,7 +1594,10 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     int rc = check_measured_tables(s);
     if (rc) return rc;
     // a call of few iterations does not need the state of a full batch (23 GB for large scenes)
-    if (uses_wavefront(s)) s->wf_batch_alloc = std::max(s->wf_batch_alloc, std::min(s->wf_batch, std::max(1, n_iterations)));
+    if (uses_wavefront(s))
+        s->wf_batch_alloc = std::max(s->wf_batch_alloc, std::min(s->wf_batch, std::max(1, n_iterations)));
+    else
+        s->batch_alloc = std::max(s->batch_alloc, std::min(s->batch, std::max(1, n_iterations)));
     if ((rc = ensure_render_buffers(s))) return rc;
     hipStream_t st = (hipStream_t)stream_;
     const Partition P = s->part;
@@ -1568,11 +1606,10 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     if (P.owned_tiles == 0 || n_iterations == 0) return PT_OK;
     const int W = s->width, H = s->height;
     const size_t J = (size_t)P.owned_tiles * kBlock;
-    int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const bool use_wavefront = uses_wavefront(s);
     if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
-    const int batch = use_wavefront ? s->wf_batch_alloc : s->batch;
+    const int batch = use_wavefront ? s->wf_batch_alloc : s->batch_alloc;
     if (use_wavefront && (rc = ensure_wavefront_buffers(s))) return rc;
     const int nbatch = (n_iterations + batch - 1) / batch;
     // Three streams: the caller's stream runs the estimator kernels back to back; the frame layout
@@ -1590,9 +1627,9 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
             HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_trace[q], 0));
             HIP_TRY(hipStreamWaitEvent(s->st_layout, s->ev_acc[q], 0));
         }
-        hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, s->st_layout, s->seed, W, H,
-                           first_iteration + k * batch, s->xstep, s->ystep, (double*)s->d_xs[q].p, (double*)s->d_ys[q].p,
-                           (int32_t*)s->d_rowstart[q].p, (int32_t*)s->d_npix[q].p, (int)(s->flags & PT_F_PIXEL_GRID));
+        launch_frame_layout(s->st_layout, s->seed, W, H, first_iteration + k * batch, B, s->xstep, s->ystep, (double*)s->d_xs[q].p,
+                            (double*)s->d_ys[q].p, (int32_t*)s->d_rowstart[q].p, (int32_t*)s->d_npix[q].p,
+                            (int)(s->flags & PT_F_PIXEL_GRID));
         HIP_TRY(hipEventRecord(s->ev_layout[q], s->st_layout));
         return PT_OK;
     };
@@ -1667,7 +1704,7 @@ int pt_render(pt_scene* s, int first_iteration, int n_iterations, double* accum_
 
 // The fused pipeline with every work buffer carved out of the device's fixed scratch array and every
 // kernel queued on the caller's stream, batch after batch: no hipMalloc / hipFree, no stream or
-// event creation.  Nothing in the scratch has to start at zero: k_frame_layout writes every table
+// event creation.  Nothing in the scratch has to start at zero: the layout kernels write every table
 // entry that is read afterwards and k_trace writes every sample slot.
 int pt_render_device_noalloc(pt_scene* s, int first_iteration, int n_iterations, double* accum_dev, void* stream_) {
     if (!s || !accum_dev) return fail(PT_ERR_INVALID, "pt_render_device_noalloc: null argument");
@@ -1677,6 +1714,9 @@ int pt_render_device_noalloc(pt_scene* s, int first_iteration, int n_iterations,
     if (rc) return rc;
     if ((int)s->bodies.size() > kMaxBodiesFused || s->pipeline == PT_PIPELINE_WAVEFRONT)
         return fail(PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: fused pipeline only (at most 127 bodies)");
+    // this device's copy of the scratch array: asked for once per device, at the first call that needs it
+    // (scenes that never come here do not depend on it), with the scene's device current
+    if (!s->scratch_ptr && (rc = scratch_address(s->device, &s->scratch_ptr))) return rc;
     hipStream_t st = (hipStream_t)stream_;
     const Partition P = s->part;
     if (P.owned_tiles == 0 || n_iterations == 0) return PT_OK;
@@ -1704,11 +1744,9 @@ int pt_render_device_noalloc(pt_scene* s, int first_iteration, int n_iterations,
     int32_t* npix = (int32_t*)carve((size_t)batch * 4);
     double* samples = (double*)carve((size_t)batch * 3 * J * 8);
     if (off > kScratchBytes) return fail(PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: work buffers exceed the fixed scratch");
-    const int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     for (int it0 = first_iteration, left = n_iterations; left > 0; it0 += batch, left -= batch) {
         const int B = std::min(batch, left);
-        hipLaunchKernelGGL(k_frame_layout, dim3(B), dim3(layout_threads), 0, st, s->seed, W, H, it0, s->xstep, s->ystep, xs, ys,
-                           rs, npix, (int)(s->flags & PT_F_PIXEL_GRID));
+        launch_frame_layout(st, s->seed, W, H, it0, B, s->xstep, s->ystep, xs, ys, rs, npix, (int)(s->flags & PT_F_PIXEL_GRID));
         dim3 grid(P.owned_tiles, B);
         if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
             hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
@@ -1845,11 +1883,9 @@ int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t*
     int rc = ensure_render_buffers(s);
     if (rc) return rc;
     const int W = s->width, H = s->height;
-    int layout_threads = std::min(1024, std::max(64, ((H + 63) / 64) * 64));
     const int CK = (W + kXStride - 1) / kXStride;
-    hipLaunchKernelGGL(k_frame_layout, dim3(1), dim3(layout_threads), 0, 0, s->seed, W, H, iteration, s->xstep, s->ystep,
-                       (double*)s->d_xs[0].p, (double*)s->d_ys[0].p, (int32_t*)s->d_rowstart[0].p, (int32_t*)s->d_npix[0].p,
-                       (int)(s->flags & PT_F_PIXEL_GRID));
+    launch_frame_layout(nullptr, s->seed, W, H, iteration, 1, s->xstep, s->ystep, (double*)s->d_xs[0].p, (double*)s->d_ys[0].p,
+                        (int32_t*)s->d_rowstart[0].p, (int32_t*)s->d_npix[0].p, (int)(s->flags & PT_F_PIXEL_GRID));
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> rs(H + 1);
     std::vector<double> ck((size_t)H * CK);
@@ -1862,7 +1898,7 @@ int pt_frame_layout(pt_scene* s, int iteration, double* ys, double* xs, int32_t*
         if (row_len[r] > 0) nr = r + 1;
         // expand the checkpoints the way k_trace does: continue the running sum (IEEE double adds)
         for (int c = 0; c < row_len[r]; ++c) {
-            volatile double x = ck[(size_t)r * CK + c / kXStride];
+            volatile double x = ck[(size_t)(c / kXStride) * H + r];
             for (int i = c & (kXStride - 1); i > 0; --i) x = x + s->xstep;
             if (s->flags & PT_F_PIXEL_GRID) x = (double)c / (double)W;
             xs[(size_t)r * W + c] = x;
