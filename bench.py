@@ -221,10 +221,12 @@ def main():
 
     proxy = args.proxy_world if world == 1 else 0
 
+    proxy_rank = 0
+
     def step():
         accum.zero_()
         if proxy:
-            r.set_partition(0, proxy, ptdist.TILE_W, ptdist.TILE_H)
+            r.set_partition(proxy_rank, proxy, ptdist.TILE_W, ptdist.TILE_H)
             r.render_device(0, IT, accum.data_ptr(), stream)
         else:
             ptdist.render_distributed(r, 0, IT, accum, rank, world, stream, exchange=exchange)
@@ -254,6 +256,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    rank_seconds = [elapsed / args.steps]
+    for proxy_rank in range(1, proxy):  # the other ranks of the proxy world, one after the other
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        rank_seconds.append((time.perf_counter() - t1) / args.steps)
     paths = traced if proxy else float(W) * H * IT * args.steps
     checksum = float(accum.sum().item()) / (W * H * 3 * IT)
     if rank == 0:
@@ -286,7 +297,8 @@ def main():
             # what one rank of `proxy` ranks does on its GPU, measured alone: value is that rank's path rate,
             # rank_seconds its time for the whole workload's share; T(1) / (N T(N)) is the efficiency
             out["proxy"] = {"world": proxy, "rank": 0, "rank_seconds_per_step": elapsed / args.steps,
-                            "rank_paths_per_step": traced / args.steps, "exchange": "not run"}
+                            "rank_paths_per_step": traced / args.steps, "exchange": "not run",
+                            "every_rank_seconds_per_step": rank_seconds, "slowest_rank_seconds_per_step": max(rank_seconds)}
             out["config"]["partition"] = f"rank 0 of {proxy} (interleaved 32x8 tiles), alone on one GPU, no exchange"
         if launches > 0:
             paths_per_launch = traced / launches  # rank 0's own launches: a per-GPU figure when N > 1

@@ -3,7 +3,8 @@
     python scripts/scaling_proxy.py <tag> [C2 C4 ...]        (on the GPU box, from the repository root)
 
 For every configuration and N in 1, 2, 4, 8 it runs `bench.py --proxy-world N` (rank 0's interleaved
-tiles of a world of N, the full iteration count, no exchange) once plainly and once under
+tiles of a world of N and then every other rank's, one after the other, the full iteration count,
+no exchange; T(N) is the slowest rank's time) once plainly and once under
 `rocprofv3 --kernel-trace --stats`, and writes gpurun_out/scaling_<tag>/<config>.json:
 T(N), efficiency = T(1) / (N T(N)), and the per-kernel average durations of the profiled run.
 The exchange is not part of the proxy: it moves W*H*3/N doubles per rank once per render.
@@ -49,7 +50,8 @@ for cfg in configs:
                 if m:
                     kernels[m.group(0)] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                      "total_ms": float(r["TotalDurationNs"]) / 1e6}
-        rows.append({"world": n, "rank_seconds": line["proxy"]["rank_seconds_per_step"],
+        rows.append({"world": n, "rank_seconds": line["proxy"]["slowest_rank_seconds_per_step"],
+                     "every_rank_seconds": line["proxy"]["every_rank_seconds_per_step"],
                      "rank_paths": line["proxy"]["rank_paths_per_step"], "rank_paths_per_s": line["value"],
                      "estimator_avg_launch_ms": line["roofline"]["avg_launch_ms"], "launches": line["roofline"]["launches"],
                      "kernels_profiled_run": kernels})
@@ -57,8 +59,9 @@ for cfg in configs:
     t1 = rows[0]["rank_seconds"]
     for r in rows:
         r["efficiency"] = t1 / (r["world"] * r["rank_seconds"])
-        r["speedup_if_ranks_run_alike"] = t1 / r["rank_seconds"]
-    res = {"config": cfg, "what": "rank 0 of N alone on one MI355X, full iteration count, no exchange; efficiency = T(1)/(N T(N))",
+        r["speedup"] = t1 / r["rank_seconds"]
+    res = {"config": cfg, "what": "every rank of N alone on one MI355X, one after the other, full iteration count, no exchange; "
+                   "T(N) = the slowest rank's time; efficiency = T(1)/(N T(N)); kernel statistics: the profiled run of the same command",
            "rows": rows}
     json.dump(res, open(os.path.join(out_dir, f"{cfg}.json"), "w"), indent=1)
     print(cfg, "efficiency", {r["world"]: round(r["efficiency"], 3) for r in rows}, flush=True)
