@@ -251,6 +251,7 @@ def main():
         traced += st["paths"]
     fence()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,6 +266,39 @@ def main():
             step()
         fence()
         rank_seconds.append((time.perf_counter() - t1) / args.steps)
+    # N > 1 checks itself: a short render through the N-rank exchange against the same render by rank 0
+    # alone (bit compare of the FP64 frames), the frame every rank ends up with, and every rank's times
+    self_check = None
+    if world > 1:
+        check_it = min(8, IT)
+        acc_d = torch.zeros_like(accum)
+        ptdist.render_distributed(r, 0, check_it, acc_d, rank, world, stream, exchange=exchange)
+        torch.cuda.synchronize()
+        digest = int(acc_d.view(torch.int64).sum().item())  # wraps; equal frames give equal digests
+        equal = None
+        if rank == 0:
+            acc_s = torch.zeros_like(accum)
+            r.set_partition(0, 1, ptdist.TILE_W, ptdist.TILE_H)
+            r.render_device(0, check_it, acc_s.data_ptr(), stream)
+            torch.cuda.synchronize()
+            equal = bool(torch.equal(acc_d.view(torch.int64), acc_s.view(torch.int64)))
+            del acc_s
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "frame_digest": digest,
+                "estimator_kernel_ms_per_step": kernel_ms / args.steps, "estimator_launches_per_step": launches / args.steps,
+                "paths_per_step": traced / args.steps, "wall_ms_per_step": 1e3 * own_elapsed / args.steps}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        km = [e["estimator_kernel_ms_per_step"] for e in every]
+        self_check = {
+            "frame_equals_single_gpu": equal,
+            "checked_iterations": check_it,
+            "every_rank_holds_the_same_frame": len({e["frame_digest"] for e in every}) == 1,
+            "rccl_ranks": dist.get_world_size(),
+            "backend": dist.get_backend(),
+            "devices": sorted({e["device"] for e in every}),
+            "estimator_kernel_ms_per_step": {"max": max(km), "min": min(km)},
+            "ranks": every,
+        }
     paths = traced if proxy else float(W) * H * IT * args.steps
     checksum = float(accum.sum().item()) / (W * H * 3 * IT)
     if rank == 0:
@@ -293,6 +327,9 @@ def main():
                 "mean_radiance": checksum,
             },
         }
+        if self_check:
+            out.update({k: self_check[k] for k in ("frame_equals_single_gpu", "rccl_ranks")})
+            out["self_check"] = self_check
         if proxy:
             # what one rank of `proxy` ranks does on its GPU, measured alone: value is that rank's path rate,
             # rank_seconds its time for the whole workload's share; T(1) / (N T(N)) is the efficiency
