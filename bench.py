@@ -131,6 +131,28 @@ def cpu_baseline(desc, scene_name, width, height, tables, seconds_target):
         "sample": f"{scene_name} scene {w}x{h}, {iters} iteration(s) on each of {cores} independent "
                   f"single-thread workers ({paths:.3g} paths, {secs:.1f} s)",
     }
+    literal = os.path.join(ROOT, "oracle", "_ref", "next_event_literal")
+    if scene_name == "nee15" and os.path.exists(literal):
+        # the literal run of the reference: `next_event <w> <h> <iterations> <thread count>` with thread count =
+        # cores and the C library's rand(), whose one generator every worker thread locks (next_event.cpp:19-22,
+        # 701-704); it squares the frame (height = argv[1], :596).  A small sample: it is several times slower
+        # than one thread alone.
+        import subprocess
+        import tempfile
+
+        lw, lit = 128, cores
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            try:
+                subprocess.run([literal, str(lw), str(lw), str(lit), str(cores)], stdout=subprocess.DEVNULL, check=True,
+                               cwd=tmp, timeout=120)
+                lsecs = time.perf_counter() - t0
+                out["literal_threads"] = {
+                    "value": float(lw) * lw * lit / lsecs, "unit": "paths/s", "threads": cores, "rng": "glibc rand(), one locked generator shared by the threads",
+                    "sample": f"next_event {lw} {lw} {lit} {cores}: {lw}x{lw} frame, {lit} iterations over {cores} threads ({lsecs:.1f} s)",
+                }
+            except (subprocess.SubprocessError, OSError) as e:
+                out["literal_threads"] = {"error": str(e)}
     out.update({k: v for k, v in info.items() if k != "cores"})
     # what the whole machine would do if every core of it ran a worker at the one-core rate
     out["all_host_cores_extrapolated"] = one_core * info["host_cpu_count"]

@@ -37,7 +37,18 @@ enum { PT_SPHERE = 0, PT_PLANE = 1, PT_RECTANGLE = 2,             /* Sphere main
                                                                       Moller-Trumbore triangle tests (PT_EST_PT only) */
 enum { PT_DIFFUSE = 0, PT_CHROME = 1, PT_GLASS = 2, PT_MEASURED = 3 }; /* Material :230, Chrome :257, Glass :269,
                                                                       MatusikBRDF.h:37 */
-enum { PT_EST_PT = 0, PT_EST_NEE = 1 };                            /* main.cpp trace() / next_event.cpp iterate() */
+enum { PT_EST_PT = 0, PT_EST_NEE = 1,                              /* main.cpp trace() / next_event.cpp iterate() */
+       PT_EST_BIDIR = 2 };                                         /* bidirectional.cpp iterate() :374-497, see below */
+/* PT_EST_BIDIR: the gather path of next_event.cpp, a light path of up to five vertices started at the
+ * chosen light (bidirectional.cpp:398-406), and one connection per (gather vertex, light-path vertex)
+ * pair, deepest first in both (:410-488).  The reference scales a connection's direct term by
+ * flux_lookup[shoot_hits.size()][shoot_i], a double[5][4] (:377-382, :484): a light path of five
+ * vertices, which is every light path of a closed scene, reads past the end of that array.  The value
+ * only multiplies emission*colour of the chosen light, which is (0,0,0) for every light of the
+ * reference's scene, and then any finite value gives the same pixel.  pt_scene_create therefore accepts
+ * PT_EST_BIDIR only for scenes in which that holds for every light (and no body is measured, every
+ * glass has ior >= 1, all numbers are finite and moderate): PT_ERR_UNSUPPORTED otherwise.  Fused
+ * pipeline only (at most 127 bodies), spheres and planes only. */
 
 /* Scene flags */
 #define PT_F_LIGHT_TRUE_CENTER 1u /* NEE shadow rays start at the light's real centre.  Default (flag
@@ -89,7 +100,7 @@ typedef struct pt_scene_desc {
     pt_camera camera;
     const pt_body* bodies;
     int32_t body_count;
-    int32_t estimator; /* PT_EST_PT | PT_EST_NEE */
+    int32_t estimator; /* PT_EST_PT | PT_EST_NEE | PT_EST_BIDIR */
     uint32_t flags;
     uint32_t reserved;
     uint64_t seed; /* replaces srand(time(NULL)) main.cpp:461 */
@@ -147,6 +158,8 @@ int pt_row_split(int height, int workers, int worker, int* start_row, int* row_c
  *                      partition; tiles beyond the owned count are zero-filled.
  *   pt_tiles_unpack:   gathered_dev (world * tiles_per_rank * 768 doubles, rank-major: the result of
  *                      an all-gather of the packed buffers) -> every pixel of accum_dev.
+ * Both go through the handle's row range as well (pt_set_rows): pixels outside it are packed as zero
+ * and left untouched on unpack.
  * Device pointers; the kernels are queued on `stream`. */
 int pt_tiles_per_rank(const pt_scene* scene, int world);
 int pt_tiles_pack(pt_scene* scene, const double* accum_dev, double* packed_dev, int tiles_capacity, void* stream);
@@ -179,7 +192,7 @@ int pt_render_device(pt_scene* scene, int first_iteration, int n_iterations, dou
  * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same
  * arguments and the same bits in accum_dev as pt_render_device; the frame tables and the batch's
  * samples live in a fixed device array of PT_NOALLOC_SCRATCH_BYTES that the library holds on every
- * GPU it runs on (its address is resolved once per device, when a scene is created there), every
+ * GPU it runs on (its address is resolved once per device, by the first such call there), every
  * kernel is queued on `stream`, and the call makes no hipMalloc/hipFree and creates no stream or
  * event.  Limits: the fused pipeline only (at most 127 bodies, PT_ERR_UNSUPPORTED otherwise), and
  * one iteration of the partition's tables and samples must fit the scratch (about 26 bytes per
@@ -240,7 +253,8 @@ int pt_save_ppm(const double* buffer, int samples, int width, int height, const 
 /* The reference's hard-coded scenes as data: "nee15" (next_event.cpp:605-689), "main32"
  * (main.cpp:473-607), "pt15" (main.cpp's estimator on the 15-body scene), "nee15_lit" (nee15 with light
  * colour 1 so the direct term is non-zero), "nee15_measured" (nee15_lit with bodies 0,1,6,7 measured),
- * "nee32" (next_event's estimator on the 32-body scene), "bipath23" (next_event's estimator on the 23-body, 10-light scene of bipath2.cpp:605-725) and
+ * "nee32" (next_event's estimator on the 32-body scene), "bidir32" (bidirectional.cpp's estimator on its own
+ * 32-body, 19-light scene, bidirectional.cpp:629-762), "bipath23" (next_event's estimator on the 23-body, 10-light scene of bipath2.cpp:605-725) and
  * "synthetic10k" / "synthetic1k" (nee15 room + 9985 / 985 extra spheres), and "light_room32" (main.cpp's estimator
  * on the 32-body scene of light_tracing.cpp:1237-1415: six balls, eight Moller-Trumbore rectangles, 18 ball
  * lights; its camera; PT_F_PIXEL_GRID).  Fills desc (desc->bodies = bodies). */

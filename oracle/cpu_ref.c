@@ -1,8 +1,9 @@
 /* TEST INFRASTRUCTURE ONLY — parity oracle, never linked into or called by the product.
  *
  * Plain-C, single-purpose CPU restatement of the reference's per-pixel radiance estimator:
- * /root/reference/main.cpp (plain path tracing) and /root/reference/next_event.cpp (path
- * tracing + next-event estimation), plus /root/reference/MatusikBRDF.h (measured BRDF lookup).
+ * /root/reference/main.cpp (plain path tracing), /root/reference/next_event.cpp (path
+ * tracing + next-event estimation) and /root/reference/bidirectional.cpp (gather path x light
+ * path connections), plus /root/reference/MatusikBRDF.h (measured BRDF lookup).
  * Every function cites the reference lines it follows.  It is pinned against the reference's
  * own code compiled here (oracle/_ref, see oracle/Makefile and tests/test_oracle_vs_ref.py)
  * and against the golden vectors under tests/golden/ generated from it.
@@ -44,7 +45,7 @@ typedef struct por_scene {
     ptor_camera camera;
     const ptor_body* bodies;
     int32_t body_count;
-    int32_t estimator; /* PTOR_EST_PT (main.cpp) or PTOR_EST_NEE (next_event.cpp) */
+    int32_t estimator; /* PTOR_EST_PT (main.cpp), PTOR_EST_NEE (next_event.cpp) or PTOR_EST_BIDIR (bidirectional.cpp) */
     uint32_t flags;
     uint32_t pad;
     uint64_t seed;
@@ -529,6 +530,82 @@ static v3 radiance_nee(const por_scene* s, const cam* c, const lightlist* lights
     return final_color;
 }
 
+/* Pixel body of bidirectional.cpp:392-494: the gather path as in next_event.cpp, a light path
+ * ("shoot") started at the chosen light, and one connection per (gather vertex, shoot vertex) pair,
+ * both loops running from the deepest vertex to the first.
+ *
+ * flux_lookup (bidirectional.cpp:377-382) is a double[5][4] indexed by [shoot_hits.size()][shoot_i]
+ * (:484).  A light path of five vertices, which is every light path of a closed scene, reads row 5,
+ * past the end of the array: the reference's value there is whatever its stack holds.  The factor
+ * only ever scales emission*colour of the chosen light (:486), which is (0,0,0) for every light of
+ * the reference's scene (:684-735), so any FINITE value gives the same pixel; frames of the
+ * reference built at -O0 and at -O3 agree bit for bit (tests/golden/bidir_ub_check.json).
+ * kFluxRow5 stands for that value here; the product refuses scenes in which it could matter. */
+static const double kFluxLookup[5][4] = {{0, 0, 0, 0},
+                                         {1.0L, 0, 0, 0},
+                                         {0.5L, 0.5L, 0, 0},
+                                         {0.5L, 0.25L, 0.25L, 0},
+                                         {0.5L, 0.25L, 0.125L, 0.125L}};
+static const double kFluxRow5 = 1.0;
+
+static v3 radiance_bidir(const por_scene* s, const cam* c, const lightlist* lights, draws* d, double x, double y,
+                         int* nrec_out, int* visible_out) {
+    v3 o = c->origin;
+    v3 dir = cam_ray_dir(c, x, y);
+    hitrec gather[POR_MAX_DEPTH], shoot[POR_MAX_DEPTH];
+    int n = 0, ns = 0;
+    while (n < POR_MAX_DEPTH) { /* trace(ray, 0, &gather_hits) :394 */
+        v3 p;
+        int hit = trace_segment(s, d, &o, &dir, &p);
+        if (hit < 0) break;
+        gather[n].point = p;
+        gather[n].body = hit;
+        n++;
+    }
+    long li = unif_long(d, (long)lights->count - 1); /* :398 */
+    int light = lights->idx[li];
+    const ptor_body* lb = &s->bodies[light];
+    /* light->shape->center through a Shape* is the never-assigned base member (0,0,0); getNormal
+     * is virtual and uses the shape's own centre (:402-404) */
+    v3 lcenter = (s->flags & POR_F_LIGHT_TRUE_CENTER) ? ld3(lb->center) : V(0.0L, 0.0L, 0.0L);
+    o = lcenter;
+    dir = random_in_hemisphere(d, shape_normal(lb, lcenter));
+    while (ns < POR_MAX_DEPTH) { /* trace(ray, 0, &shoot_hits) :406 */
+        v3 p;
+        int hit = trace_segment(s, d, &o, &dir, &p);
+        if (hit < 0) break;
+        shoot[ns].point = p;
+        shoot[ns].body = hit;
+        ns++;
+    }
+    v3 lterm = mul(ld3(lb->emission), ld3(lb->color));
+    v3 final_color = V(0.0L, 0.0L, 0.0L);
+    int vis = 0;
+    for (int gi = n - 1; gi >= 0; gi--) {
+        for (int si = ns - 1; si >= 0; si--) {
+            v3 G = gather[gi].point, S = shoot[si].point;
+            v3 bdir = normalize(sub(G, S)); /* bi_ray :415-417 */
+            double mint;
+            int hit = nearest(s, S, bdir, light, &mint); /* :419-433 */
+            if (hit != gather[gi].body) continue;        /* :435-437 */
+            vis |= 1 << (gi * POR_MAX_DEPTH + si);
+            const ptor_body* hb = &s->bodies[hit];
+            v3 next_point = (gi >= 1) ? gather[gi - 1].point : cam_point(c, x, y); /* :449-454 */
+            v3 gather_brdf = bounce(hb, d, bdir, normalize(sub(next_point, G)));   /* :463-465 */
+            double gather_flux = fabs(dot(gather_brdf, shape_normal(hb, G)));      /* :467 */
+            const ptor_body* sb = &s->bodies[shoot[si].body];
+            v3 shoot_brdf = bounce(sb, d, bdir, normalize(sub(G, S)));             /* :470-472 */
+            double shoot_flux = fabs(dot(shoot_brdf, shape_normal(sb, S)));        /* :474 */
+            double lookup = ns < 5 ? kFluxLookup[ns][si] : kFluxRow5;
+            double flux = lookup * gather_flux * shoot_flux;                       /* :484 */
+            final_color = add(mul(add(final_color, muls(lterm, flux)), ld3(hb->color)), ld3(hb->emission)); /* :486-487 */
+        }
+    }
+    if (nrec_out) *nrec_out = n | (ns << 8);
+    if (visible_out) *visible_out = vis;
+    return final_color;
+}
+
 /* ---- frame loop: Renderer::iterate main.cpp:349-365 / next_event.cpp:374-473 -------- */
 
 static void stream(draws* d, const por_scene* s, uint32_t it, uint32_t dom, uint32_t idx) {
@@ -554,6 +631,8 @@ static void iterate(const por_scene* s, const cam* c, const lightlist* lights, d
             v3 col;
             if (s->estimator == PTOR_EST_NEE)
                 col = radiance_nee(s, c, lights, d, x, y, NULL, NULL, NULL);
+            else if (s->estimator == PTOR_EST_BIDIR)
+                col = radiance_bidir(s, c, lights, d, x, y, NULL, NULL);
             else
                 col = radiance_pt(s, d, c->origin, cam_ray_dir(c, x, y));
             buffer[3 * i + 0] += col.x;
@@ -722,6 +801,11 @@ void por_trace_paths(const por_scene* s, const int* it_idx2, const double* xy, i
         v3 col;
         if (s->estimator == PTOR_EST_NEE) {
             col = radiance_nee(s, &c, &lights, &d, xy[2 * k], xy[2 * k + 1], recs, &nr, &vis);
+        } else if (s->estimator == PTOR_EST_BIDIR) {
+            /* no records: nrec = gather count | shoot count << 8, visible bit gi * 5 + si per connection */
+            int counts = 0;
+            col = radiance_bidir(s, &c, &lights, &d, xy[2 * k], xy[2 * k + 1], &counts, &vis);
+            nr = counts;
         } else {
             v3 o = c.origin, dir = cam_ray_dir(&c, xy[2 * k], xy[2 * k + 1]);
             draws d2 = d;

@@ -9,7 +9,7 @@
 enum { PTOR_SPHERE = 0, PTOR_PLANE = 1, PTOR_RECTANGLE = 2 /* Rectangle(p1,p2,p3,p4) raytrace3.cpp:244-276 */,
        PTOR_RECTANGLE_MT = 3 /* Rectangle(p1,p2,p3,p4) light_tracing.cpp:477-575 */ };
 enum { PTOR_DIFFUSE = 0, PTOR_CHROME = 1, PTOR_GLASS = 2, PTOR_MEASURED = 3 };
-enum { PTOR_EST_PT = 0, PTOR_EST_NEE = 1 };
+enum { PTOR_EST_PT = 0, PTOR_EST_NEE = 1, PTOR_EST_BIDIR = 2 /* bidirectional.cpp:374-497 */ };
 
 typedef struct ptor_body {
     int32_t shape;

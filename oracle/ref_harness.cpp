@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY — harness around the UNMODIFIED reference sources.
 //
-// The reference programs (main.cpp, next_event.cpp, raytrace3.cpp) are textually included (from where they lie under the
+// The reference programs (main.cpp, next_event.cpp, raytrace3.cpp, bidirectional.cpp) are textually included (from where they lie under the
 // reference checkout; nothing is copied) into separate namespaces, with `main` renamed by
 // the preprocessor.  The scene each program builds on the stack of its main()
 // (/root/reference/main.cpp:473-607, next_event.cpp:605-689) is borrowed through the boost
@@ -30,7 +30,7 @@
 #include "shim/ptor_boost_shim.hpp"
 
 #ifndef PTOR_REF_MAIN
-#error "define PTOR_REF_MAIN / PTOR_REF_NEE / PTOR_REF_BRDF as quoted paths into the reference checkout"
+#error "define PTOR_REF_MAIN / PTOR_REF_NEE / PTOR_REF_RT3 / PTOR_REF_BIDIR / PTOR_REF_BRDF as quoted paths into the reference checkout"
 #endif
 
 namespace ref_pt {
@@ -53,6 +53,14 @@ namespace ref_rt3 {
 #include PTOR_REF_RT3
 #undef main
 }  // namespace ref_rt3
+
+// bidirectional.cpp: next_event.cpp's gather path plus a light sub-path and the gather x shoot
+// connection loop (bidirectional.cpp:374-497), on its own 32-body scene (:683-762).
+namespace ref_bidir {
+#define main ref_main
+#include PTOR_REF_BIDIR
+#undef main
+}  // namespace ref_bidir
 
 #undef _MATUSIKBRDFREADER_H_
 namespace ref_brdf {
@@ -114,6 +122,24 @@ struct RT3 {
     typedef ref_rt3::Camera Camera;
     static int run_main(int argc, const char** argv) { return ref_rt3::ref_main(argc, argv); }
     static void save(V3* b, int s, int w, int h) { ref_rt3::save(b, s, w, h); }
+};
+
+struct BIDIR {
+    enum { prog = 3 };
+    typedef ref_bidir::V3 V3;
+    typedef ref_bidir::Ray Ray;
+    typedef ref_bidir::Scene Scene;
+    typedef ref_bidir::Renderer Renderer;
+    typedef ref_bidir::Body Body;
+    typedef ref_bidir::Shape Shape;
+    typedef ref_bidir::Plane Plane;
+    typedef ref_bidir::Sphere Sphere;
+    typedef ref_bidir::Material Material;
+    typedef ref_bidir::Chrome Chrome;
+    typedef ref_bidir::Glass Glass;
+    typedef ref_bidir::Camera Camera;
+    static int run_main(int argc, const char** argv) { return ref_bidir::ref_main(argc, argv); }
+    static void save(V3* b, int s, int w, int h) { ref_bidir::save(b, s, w, h); }
 };
 
 // main.cpp / next_event.cpp keep `Body** objects` + body_count, raytrace3.cpp a vector<Body*>
@@ -374,6 +400,7 @@ long long ptor_render_custom(int prog, const ptor_body* bodies, int n, int W, in
     if (prog == 2) return render_custom<RT3>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out);
     for (int i = 0; i < n; i++)
         if (bodies[i].shape == PTOR_RECTANGLE) return -1;  // only raytrace3.cpp has the shape
+    if (prog == 3) return render_custom<BIDIR>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out);
     return prog == 0 ? render_custom<PT>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out)
                      : render_custom<NEE>(bodies, n, W, H, first_it, n_it, mode, seed, buffer_out);
 }
@@ -383,9 +410,10 @@ int ptor_set_scratch(const char* dir) {
     return 0;
 }
 
-// prog: 0 = main.cpp, 1 = next_event.cpp, 2 = raytrace3.cpp.  Returns body count.
+// prog: 0 = main.cpp, 1 = next_event.cpp, 2 = raytrace3.cpp, 3 = bidirectional.cpp.  Returns body count.
 int ptor_scene_bodies(int prog, ptor_body* out, int cap, ptor_camera* cam) {
     if (prog == 2) return scene_bodies<RT3>(out, cap, cam);
+    if (prog == 3) return scene_bodies<BIDIR>(out, cap, cam);
     return prog == 0 ? scene_bodies<PT>(out, cap, cam) : scene_bodies<NEE>(out, cap, cam);
 }
 
@@ -461,6 +489,7 @@ int ptor_bounce(int prog, int body, const double* ray6, const double* normal3, c
 long long ptor_render(int prog, int W, int H, int first_it, int n_it, int mode, uint64_t seed,
                       const int* script, int script_len, double* buffer_out) {
     if (prog == 2) return render<RT3>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out);
+    if (prog == 3) return render<BIDIR>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out);
     return prog == 0 ? render<PT>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out)
                      : render<NEE>(W, H, first_it, n_it, mode, seed, script, script_len, buffer_out);
 }

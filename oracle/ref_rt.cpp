@@ -36,8 +36,8 @@ struct RtState {
 
 thread_local RtState g;
 
-void* g_addr_getray[3] = {0, 0, 0};
-void* g_addr_iadd[3] = {0, 0, 0};
+void* g_addr_getray[4] = {0, 0, 0, 0};
+void* g_addr_iadd[4] = {0, 0, 0, 0};
 
 }  // namespace
 
@@ -117,7 +117,7 @@ PTOR_NOINST void __wrap_srand(unsigned) {}
 // -finstrument-functions hooks (only the hooked build of ref_harness.cpp emits calls).
 PTOR_NOINST void __cyg_profile_func_enter(void* fn, void*) {
     if (g.mode != PTOR_MODE_PIXEL) return;
-    if (fn == g_addr_getray[0] || fn == g_addr_getray[1] || fn == g_addr_getray[2]) {
+    if (fn == g_addr_getray[0] || fn == g_addr_getray[1] || fn == g_addr_getray[2] || fn == g_addr_getray[3]) {
         // Camera::getRay is called exactly once per pixel, first thing in the pixel body.
         ptor_rng_init(&g.rng, g.seed, g.iteration, PTOR_DOM_PIXEL, g.pixel++);
         g.in_pixel = true;
@@ -126,7 +126,7 @@ PTOR_NOINST void __cyg_profile_func_enter(void* fn, void*) {
 
 PTOR_NOINST void __cyg_profile_func_exit(void* fn, void*) {
     if (g.mode != PTOR_MODE_PIXEL) return;
-    if (fn == g_addr_iadd[0] || fn == g_addr_iadd[1] || fn == g_addr_iadd[2]) {
+    if (fn == g_addr_iadd[0] || fn == g_addr_iadd[1] || fn == g_addr_iadd[2] || fn == g_addr_iadd[3]) {
         // V3::iadd is called exactly once per pixel, last thing in the pixel body.
         g.in_pixel = false;
     }

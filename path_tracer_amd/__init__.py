@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PTGPU_LIB") or os.path.join(_HERE, "libptgpu.so")
 
 SPHERE, PLANE, RECTANGLE, RECTANGLE_MT = 0, 1, 2, 3  # RECTANGLE_MT: light_tracing.cpp:477-575
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3
-EST_PT, EST_NEE = 0, 1
+EST_PT, EST_NEE, EST_BIDIR = 0, 1, 2  # EST_BIDIR: bidirectional.cpp:374-497
 F_LIGHT_TRUE_CENTER = 1
 F_RAYTRACE3 = 2  # raytrace3.cpp's path tracer: hit threshold 1e-7, see include/ptgpu.h
 F_PIXEL_GRID = 4  # samples on the pixel grid as Renderer::ray_iterate takes them, light_tracing.cpp:785-790

@@ -1,11 +1,13 @@
-// Drop-in executables for three of the reference's programs:
+// Drop-in executables for four of the reference's programs:
 //   main        <width> <height> <iterations> <thread count>   (main.cpp:460-471, 642-656)
 //   next_event  <width> <height> <iterations> <thread count>   (next_event.cpp:587-598, 701-712)
+//   bidirectional <width> <height> <iterations> <thread count> (bidirectional.cpp:611-623, 776-785:
+//               next_event's command line, worker split, save() and file name; its own scene and estimator)
 //   raytrace3   <width> <height> <iterations> <thread count>   (raytrace3.cpp:906-918, 1021-1036;
 //               main's command line, worker split and save(), its own scene and hit threshold)
 // Same positional arguments, same hard-coded scenes, same output file names and PPM bytes; the
-// per-pixel estimator runs on the GPU through the ptgpu C ABI.  Built three times from this file
-// (-DPT_PROG_NEE selects next_event, -DPT_PROG_RT3 raytrace3).
+// per-pixel estimator runs on the GPU through the ptgpu C ABI.  Built four times from this file
+// (-DPT_PROG_NEE selects next_event, -DPT_PROG_NEE -DPT_PROG_BIDIR bidirectional, -DPT_PROG_RT3 raytrace3).
 //
 // <thread count> keeps the reference's arithmetic: each of the T workers renders
 // iterations/T full frames into a private buffer and the buffers are summed (main.cpp:436-458);
@@ -88,7 +90,7 @@ int main(int argc, const char* argv[]) {
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else if (a == "--quiet") quiet = true;
         else if (a == "--progressive") progressive = true;
-#ifdef PT_PROG_NEE
+#if defined(PT_PROG_NEE) && !defined(PT_PROG_BIDIR)
         else if (a == "--literal-height") height = width;
 #endif
         else {
@@ -100,8 +102,12 @@ int main(int argc, const char* argv[]) {
     const bool user_out = !out.empty();
     (void)user_out;
 #ifdef PT_PROG_NEE
+#ifdef PT_PROG_BIDIR
+    const char* preset = "bidir32";
+#else
     const char* preset = "nee15";
-    int per_worker = iterations / thread_count;                          // next_event.cpp:703
+#endif
+    int per_worker = iterations / thread_count;                          // next_event.cpp:703, bidirectional.cpp:778
     if (out.empty()) out = "output.ppm";                                 // next_event.cpp:535
 #else
 #ifdef PT_PROG_RT3

@@ -61,7 +61,7 @@ constexpr int kBrdfN = 90 * 90 * 180;  // MatusikBRDF.h:24-26
 
 enum { kSphere = 0, kPlane = 1, kPlaneX = 2, kPlaneY = 3, kPlaneZ = 4, kRect = 5, kRectMT = 6 };  // 2..4: device-only, normal = +-e_k; 5: raytrace3's Rectangle; 6: light_tracing's
 enum { kDiffuse = 0, kChrome = 1, kGlass = 2, kMeasured = 3 };
-enum { kEstPT = 0, kEstNEE = 1 };
+enum { kEstPT = 0, kEstNEE = 1, kEstBidir = 2 };
 enum { kDomPixel = 0, kDomRow = 1, kDomFrame = 2, kDomSeq = 3 };
 
 // ---- V3: main.cpp:50-103 ---------------------------------------------------------------
@@ -1537,6 +1537,75 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
             const V3 sc = ((twin >> g) & 1u) ? mk(flux_nan(), flux_nan(), flux_nan()) : scale;
             L = add(mul(add(L, sc), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));  // next_event.cpp:452-462
         }
+    }
+    return L;
+}
+
+// Pixel body of bidirectional.cpp:392-494 for scenes whose direct term is dead everywhere
+// (DScene::nee_emission_only, which pt_scene_create demands of this estimator): the gather path
+// (:394, trace() :515-554), the light pick (:398), a light path started at the chosen light in a random
+// direction of the hemisphere about its normal (:402-406), and for every (gather vertex, light-path
+// vertex) pair a scan from the light-path vertex towards the gather vertex with the light left out
+// (:415-437).  A visible pair applies L = (L + (Le*Lc)*flux) * c + e of the gather vertex's body
+// (:486-487).  With Le*Lc exactly zero and flux finite the added term is a zero, nothing after the
+// light path reads the random stream, and the two bounce() calls that make flux (:463-474) are dead:
+// the pixel depends only on how many light-path vertices see each gather vertex.  Gather vertices
+// deeper than the deepest emitting one leave L at zero and are not connected at all.  As in
+// trace_path_nee_compact, a chrome or glass gather vertex that coincides with the vertex before it
+// ("twin") makes the reference's flux NaN (it reflects about a normalised zero vector): such vertices
+// count like emitting ones and turn L into NaN when they are seen.  (flux also carries
+// flux_lookup[shoot_hits.size()][shoot_i], :484, which the reference reads past the end of the array
+// when the light path has five vertices; any finite value there gives these results.)
+// The connections are made while the light path is traced, vertex by vertex, so its positions are
+// never stored: the order of the pairs does not matter, only the count per gather vertex.
+PTD_INLINE V3 trace_path_bidir(const DScene& S, Draws& dr, double x, double y, const Records& rec) {
+    int n = 0, need = 0;
+    unsigned twin = 0;
+    V3 o = ld3(S.cam_o);
+    V3 prev = cam_point(S, x, y);
+    V3 d = normalize(sub(prev, o));  // Camera::getRay main.cpp:154-157
+#pragma unroll 1
+    for (; n < kMaxDepth; ++n) {
+        double mint;
+        int hit = nearest_hit_any(S, o, d, mint);
+        if (hit < 0) break;
+        const DMat& m = S.mat[hit];
+        V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);
+        rec.put(n, point, hit);
+        const bool tw = (m.material != kDiffuse) & same_point(point, prev);
+        twin |= (tw ? 1u : 0u) << n;
+        if (m.emits | tw) need = n + 1;
+        prev = point;
+    }
+    const int light = pick_light(S, dr);
+    // light->shape->center through a Shape* is (0,0,0) unless the scene asks for the real centre;
+    // getNormal is virtual and uses the shape's own centre (bidirectional.cpp:402-404)
+    o = light_origin(S, light);
+    d = random_in_hemisphere(dr, shape_normal(S.geom[light], o));
+    unsigned seen = 0;  // three bits per gather vertex: the number of light-path vertices that see it
+#pragma unroll 1
+    for (int ns = 0; ns < kMaxDepth; ++ns) {
+        double mint;
+        int hit = nearest_hit_any(S, o, d, mint);
+        if (hit < 0) break;
+        const V3 sp = shade_hit(S.geom[hit], S.mat[hit], dr, o, d, mint);
+#pragma unroll 1
+        for (int g = 0; g < need; ++g) {
+            const V3 bd = normalize(sub(rec.point(g), sp));  // bi_ray :415-417
+            double t;
+            const int h = nearest_hit<false>(S, sp, bd, light, t);
+            seen += (h == rec.body(g) ? 1u : 0u) << (3 * g);  // :435-437
+        }
+    }
+    V3 L = mk(0.0, 0.0, 0.0);
+    const V3 scale = muls(light_term(S, light), 0.0);
+#pragma unroll 1
+    for (int g = need - 1; g >= 0; --g) {
+        const DMat& m = S.mat[rec.body(g)];
+        const V3 sc = ((twin >> g) & 1u) ? mk(flux_nan(), flux_nan(), flux_nan()) : scale;
+#pragma unroll 1
+        for (unsigned k = (seen >> (3 * g)) & 7u; k > 0; --k)
+            L = add(mul(add(L, sc), mk(m.colr, m.colg, m.colb)), mk(m.emr, m.emg, m.emb));  // :486-487
     }
     return L;
 }

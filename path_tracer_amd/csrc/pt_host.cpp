@@ -221,6 +221,26 @@ void scene_main32(Builder& B) {
     emitter(B.sphere(0.63333, -2.5, 2.1, 0.1), e[0], e[1], e[2]);   // front2     :586
 }
 
+// bidirectional.cpp:629-762, array order :756-761: next_event's bodies with the top-left divider where
+// main.cpp has it (:693) and main.cpp's 18 sphere lights in main.cpp's order (:697-745).
+void scene_bidir32(Builder& B) {
+    common_bodies(B, true);
+    if (B.overflow) return;
+    Builder::set3(B.out[12].center, -1.8, 4.4, 2.4);  // top-left divider bidirectional.cpp:693
+    const double e[3] = {2.0, 1.87, 1.69};
+    emitter(B.sphere(1.9, 3.625, 2.1, 0.1), e[0], e[1], e[2]);      // right  :697
+    emitter(B.sphere(-1.9, 3.625, 2.1, 0.1), e[0], e[1], e[2]);     // left   :701
+    emitter(B.sphere(-0.63333, 4.5, 2.1, 0.1), e[0], e[1], e[2]);   // back   :730
+    emitter(B.sphere(0.63333, 4.5, 2.1, 0.1), e[0], e[1], e[2]);    // back2  :734
+    const double ys[6] = {2.75, 1.875, 1.0, 0.125, -0.75, -1.625};  // right2..7 / left2..7 :705-728
+    for (double y : ys) {
+        emitter(B.sphere(1.9, y, 2.1, 0.1), e[0], e[1], e[2]);
+        emitter(B.sphere(-1.9, y, 2.1, 0.1), e[0], e[1], e[2]);
+    }
+    emitter(B.sphere(-0.63333, -2.5, 2.1, 0.1), e[0], e[1], e[2]);  // front  :738
+    emitter(B.sphere(0.63333, -2.5, 2.1, 0.1), e[0], e[1], e[2]);   // front2 :742
+}
+
 // bipath2.cpp:605-725, array order :722-724: the common bodies with next_event's small spheres,
 // main's top-left divider position, a dimmer top light that still counts as a light
 // (emission.x == 1.0 >= 1.0, next_event.cpp:364) and nine sphere lights — the array lists a tenth,
@@ -352,6 +372,9 @@ int pt_preset_scene(const char* name, int width, int height, pt_scene_desc* desc
     } else if (s == "nee32") {  // next_event's estimator on the 32-body scene (bidirectional.cpp:755-760 lists the same bodies)
         desc->estimator = PT_EST_NEE;
         scene_main32(B);
+    } else if (s == "bidir32") {  // bidirectional.cpp as shipped
+        desc->estimator = PT_EST_BIDIR;
+        scene_bidir32(B);
     } else if (s == "bipath23") {  // next_event's estimator on bipath2.cpp's 23-body scene
         desc->estimator = PT_EST_NEE;
         scene_bipath23(B);

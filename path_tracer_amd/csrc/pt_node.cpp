@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,7 @@ struct pt_node {
     std::vector<hipStream_t> stream;
     std::vector<double*> accum, packed;
     double* gathered = nullptr;  // on device[0]: n * tiles * 768 doubles
+    double* staging = nullptr;   // pinned host copy of the frame: one memcpy from the caller, then DMA to every device
     std::vector<ncclComm_t> comm;
 };
 
@@ -68,6 +70,7 @@ int pt_node_destroy(pt_node* nd) {
         if (d == 0 && nd->gathered) (void)hipFree(nd->gathered);
         if (d < (int)nd->stream.size() && nd->stream[d]) (void)hipStreamDestroy(nd->stream[d]);
     }
+    if (nd->staging) (void)hipHostFree(nd->staging);
     delete nd;
     return PT_OK;
 }
@@ -76,6 +79,8 @@ int pt_node_create(const pt_scene_desc* desc, const int* devices, int n_devices,
     if (!desc || !out || n_devices < 1) return fail(PT_ERR_INVALID, "pt_node_create: bad argument");
     int available = 0;
     NODE_HIP(hipGetDeviceCount(&available));
+    int entry_device = 0;  // the caller's current device, restored before returning
+    NODE_HIP(hipGetDevice(&entry_device));
     pt_node* nd = new (std::nothrow) pt_node();
     if (!nd) return fail(PT_ERR_NOMEM, "pt_node_create: out of host memory");
     nd->n = n_devices;
@@ -100,9 +105,14 @@ int pt_node_create(const pt_scene_desc* desc, const int* devices, int n_devices,
     nd->accum.assign(n_devices, nullptr);
     nd->packed.assign(n_devices, nullptr);
     nd->comm.assign(n_devices, nullptr);
+    auto restore = [&]() {
+        (void)pt_set_device(entry_device);  // also the library's thread-local device for later pt_scene_create calls
+        (void)hipSetDevice(entry_device);
+    };
     auto bail = [&](int rc) {
         const std::string keep = g_node_err;
         pt_node_destroy(nd);
+        restore();
         g_node_err = keep;
         return rc;
     };
@@ -120,9 +130,12 @@ int pt_node_create(const pt_scene_desc* desc, const int* devices, int n_devices,
             e = hipMalloc((void**)&nd->gathered, (size_t)n_devices * nd->tiles * kTileDoubles * sizeof(double));
         if (e != hipSuccess) return bail(fail(PT_ERR_NOMEM, std::string("pt_node_create: ") + hipGetErrorString(e)));
     }
+    hipError_t he = hipHostMalloc((void**)&nd->staging, frame_bytes, hipHostMallocPortable);
+    if (he != hipSuccess) return bail(fail(PT_ERR_NOMEM, std::string("pt_node_create: hipHostMalloc: ") + hipGetErrorString(he)));
     // one communicator per device, all in this process
     ncclResult_t ne = ncclCommInitAll(nd->comm.data(), n_devices, nd->device.data());
     if (ne != ncclSuccess) return bail(fail(PT_ERR_DEVICE, std::string("ncclCommInitAll: ") + ncclGetErrorString(ne)));
+    restore();
     *out = nd;
     return PT_OK;
 }
@@ -137,31 +150,57 @@ int pt_node_render(pt_node* nd, int first_iteration, int n_iterations, double* a
     if (!nd || !accum_host) return fail(PT_ERR_INVALID, "pt_node_render: null argument");
     const size_t frame_bytes = (size_t)nd->width * nd->height * 3 * sizeof(double);
     const size_t count = (size_t)nd->tiles * kTileDoubles;
+    int entry_device = 0;
+    NODE_HIP(hipGetDevice(&entry_device));
+    // Whatever happens, nothing of this call is left in flight when it returns: the caller owns
+    // accum_host again, and the next render starts from settled accumulators.
+    auto finish = [&](int rc) {
+        std::string keep = g_node_err;
+        for (int d = 0; d < nd->n; ++d) {
+            hipError_t e = hipSetDevice(nd->device[d]);
+            if (e == hipSuccess) e = hipStreamSynchronize(nd->stream[d]);
+            if (e != hipSuccess && rc == PT_OK) {  // the first failure is the one reported
+                rc = PT_ERR_DEVICE;
+                keep = std::string("pt_node_render: device ") + std::to_string(nd->device[d]) + ": " + hipGetErrorString(e);
+            }
+        }
+        (void)hipSetDevice(entry_device);
+        g_node_err = keep;
+        return rc;
+    };
+#define NODE_TRY_HIP(expr)                                                                                         \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess) return finish(fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+#define NODE_TRY_PT(expr)                                             \
+    do {                                                              \
+        int rc_ = (expr);                                             \
+        if (rc_ != PT_OK) return finish(fail(rc_, pt_last_error())); \
+    } while (0)
     // Every device starts from the caller's accumulator and adds its own tiles' samples in
     // iteration order, exactly as a single device would; the other pixels are never read back.
+    memcpy(nd->staging, accum_host, frame_bytes);
     for (int d = 0; d < nd->n; ++d) {
-        NODE_HIP(hipSetDevice(nd->device[d]));
-        NODE_HIP(hipMemcpyAsync(nd->accum[d], accum_host, frame_bytes, hipMemcpyHostToDevice, nd->stream[d]));
-        NODE_PT(pt_render_device(nd->scene[d], first_iteration, n_iterations, nd->accum[d], nd->stream[d]));
-        NODE_PT(pt_tiles_pack(nd->scene[d], nd->accum[d], nd->packed[d], nd->tiles, nd->stream[d]));
+        NODE_TRY_HIP(hipSetDevice(nd->device[d]));
+        NODE_TRY_HIP(hipMemcpyAsync(nd->accum[d], nd->staging, frame_bytes, hipMemcpyHostToDevice, nd->stream[d]));
+        NODE_TRY_PT(pt_render_device(nd->scene[d], first_iteration, n_iterations, nd->accum[d], nd->stream[d]));
+        NODE_TRY_PT(pt_tiles_pack(nd->scene[d], nd->accum[d], nd->packed[d], nd->tiles, nd->stream[d]));
     }
-    NODE_NCCL(ncclGroupStart());
-    for (int d = 0; d < nd->n; ++d) {
-        ncclResult_t e = ncclGather(nd->packed[d], nd->gathered, count, ncclDouble, 0, nd->comm[d], nd->stream[d]);
-        if (e != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return fail(PT_ERR_DEVICE, std::string("ncclGather: ") + ncclGetErrorString(e));
-        }
-    }
-    NODE_NCCL(ncclGroupEnd());
-    NODE_HIP(hipSetDevice(nd->device[0]));
-    NODE_PT(pt_tiles_unpack(nd->scene[0], nd->n, nd->tiles, nd->gathered, nd->accum[0], nd->stream[0]));
-    NODE_HIP(hipMemcpyAsync(accum_host, nd->accum[0], frame_bytes, hipMemcpyDeviceToHost, nd->stream[0]));
-    for (int d = 0; d < nd->n; ++d) {
-        NODE_HIP(hipSetDevice(nd->device[d]));
-        NODE_HIP(hipStreamSynchronize(nd->stream[d]));
-    }
-    return PT_OK;
+    ncclResult_t ne = ncclGroupStart();
+    for (int d = 0; d < nd->n && ne == ncclSuccess; ++d)
+        ne = ncclGather(nd->packed[d], nd->gathered, count, ncclDouble, 0, nd->comm[d], nd->stream[d]);
+    const ncclResult_t ge = ncclGroupEnd();  // always closes the group that was opened
+    if (ne == ncclSuccess) ne = ge;
+    if (ne != ncclSuccess) return finish(fail(PT_ERR_DEVICE, std::string("ncclGather: ") + ncclGetErrorString(ne)));
+    NODE_TRY_HIP(hipSetDevice(nd->device[0]));
+    NODE_TRY_PT(pt_tiles_unpack(nd->scene[0], nd->n, nd->tiles, nd->gathered, nd->accum[0], nd->stream[0]));
+    NODE_TRY_HIP(hipMemcpyAsync(nd->staging, nd->accum[0], frame_bytes, hipMemcpyDeviceToHost, nd->stream[0]));
+    const int rc = finish(PT_OK);
+    if (rc == PT_OK) memcpy(accum_host, nd->staging, frame_bytes);
+    return rc;
+#undef NODE_TRY_HIP
+#undef NODE_TRY_PT
 }
 
 }  // extern "C"

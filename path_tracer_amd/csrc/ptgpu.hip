@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
     rec.tid = tid;
     if (COMPACT) {
         rgb = trace_path_nee_compact(S, dr, valid, x, y, rec, s_slots + (tid & ~63));
+    } else if (EST == kEstBidir) {
+        if (valid) rgb = trace_path_bidir(S, dr, x, y, rec);
     } else if (valid) {
         PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
         rgb = R.rgb;
@@ -778,9 +780,20 @@ struct SceneUpload {
                 if (!in_slab[i]) scan_planes.push_back(g);
             }
         }
+        // Neither list is ever empty: an empty one gets records that can never be hit, so that the scan
+        // loops always have a first iteration.  (The compiler turns `for (k < n)` into a guard and a
+        // count-down loop and may keep the guard, a wave-uniform boolean, as a lane mask taken while only
+        // some lanes were active; a later scan by other lanes then reads it as "n > 0" and would enter the
+        // loop with a count of zero.  Seen in the bidirectional kernel on a scene without planes.)
+        if (scan_planes.empty()) {
+            DGeom g;
+            memset(&g, 0, sizeof g);
+            g.shape = kPlane;  // normal (0,0,0): n.d = 0 lies inside the parallel cut-off of Plane::intersect, never a hit
+            g.pad[0] = -1;
+            scan_planes.push_back(g);
+        }
         n_planes = (int)scan_planes.size();
-    n_spheres = (int)scan_spheres.size();
-        if (n_spheres & 1) {
+        while (scan_spheres.empty() || (scan_spheres.size() & 1)) {
             DGeom g;
             memset(&g, 0, sizeof g);
             g.nx = -1.0;  // radius^2 < 0: the exact test cannot pass either
@@ -789,6 +802,7 @@ struct SceneUpload {
             g.pad[0] = -1;
             scan_spheres.push_back(g);
         }
+        n_spheres = (int)scan_spheres.size();
         // the origin-dependent term of every record for the origin (0,0,0) (see origin0_term)
         auto put_term = [](DGeom& g, double v) {
             uint64_t u;
@@ -1079,8 +1093,6 @@ struct SceneUpload {
 
     // Device copies of the lists and the scalar fields of DScene.
     int upload() {
-        if (scan_planes.empty()) scan_planes.resize(1);
-        if (scan_spheres.empty()) scan_spheres.resize(2);
         if (scan_screen.empty()) scan_screen.resize(1);
         if (scan_screen0.empty()) scan_screen0.resize(1);
         int rc;
@@ -1175,7 +1187,7 @@ struct SceneUpload {
             moderate = moderate && std::isfinite(s->camera.origin[k]) && std::isfinite(s->camera.topleft[k]) &&
                        std::isfinite(s->camera.topright[k]) && std::isfinite(s->camera.bottomleft[k]);
         D.flux_finite = moderate ? 1 : 0;
-        bool dead = s->estimator == PT_EST_NEE && s->lights.size() >= 2 && moderate;
+        bool dead = (s->estimator == PT_EST_NEE ? s->lights.size() >= 2 : s->estimator == PT_EST_BIDIR) && moderate;
         for (int i = 0; i < n && dead; ++i) {
             const pt_body& b = s->bodies[i];
             if (b.material == PT_MEASURED) dead = false;
@@ -1356,6 +1368,21 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     return PT_OK;
 }
 
+// Queues the fused estimator kernel of the scene's estimator and material mix for one batch.
+void launch_trace(const pt_scene* s, dim3 grid, hipStream_t st, const Partition& P, int it0, const double* xs, const double* ys,
+                  const int32_t* rs, const int32_t* npix, double* samples, size_t J) {
+    if (s->estimator == PT_EST_BIDIR)
+        hipLaunchKernelGGL((k_trace<kEstBidir, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+    else if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
+        hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+    else if (s->estimator == PT_EST_NEE && s->has_measured)
+        hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+    else if (s->estimator == PT_EST_NEE)
+        hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+    else
+        hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+}
+
 int check_measured_tables(const pt_scene* s) {
     for (const pt_body& b : s->bodies)
         if (b.material == PT_MEASURED) {
@@ -1382,7 +1409,8 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     if (desc->width < 1 || desc->height < 1) return fail(PT_ERR_INVALID, "pt_scene_create: width/height must be >= 1");
     if ((int64_t)desc->width * desc->height > (int64_t)1 << 28) return fail(PT_ERR_INVALID, "pt_scene_create: frame too large");
     if (desc->body_count < 1 || !desc->bodies) return fail(PT_ERR_INVALID, "pt_scene_create: no bodies");
-    if (desc->estimator != PT_EST_PT && desc->estimator != PT_EST_NEE) return fail(PT_ERR_INVALID, "pt_scene_create: estimator");
+    if (desc->estimator != PT_EST_PT && desc->estimator != PT_EST_NEE && desc->estimator != PT_EST_BIDIR)
+        return fail(PT_ERR_INVALID, "pt_scene_create: estimator");
     pt_scene* s = new (std::nothrow) pt_scene();
     if (!s) return fail(PT_ERR_NOMEM, "pt_scene_create: out of host memory");
     s->device = g_device;
@@ -1424,9 +1452,13 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
         delete s;
         return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: PT_F_RAYTRACE3 applies to PT_EST_PT");
     }
-    if (s->estimator == PT_EST_NEE && s->lights.empty()) {
+    if (s->estimator != PT_EST_PT && s->lights.empty()) {
         delete s;
-        return fail(PT_ERR_INVALID, "pt_scene_create: next-event estimation needs a body with emission >= 1");
+        return fail(PT_ERR_INVALID, "pt_scene_create: next-event and bidirectional estimation need a body with emission >= 1");
+    }
+    if (s->estimator == PT_EST_BIDIR && (int)s->bodies.size() > kMaxBodiesFused) {
+        delete s;
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: the bidirectional estimator runs the fused pipeline, at most 127 bodies");
     }
     // Loop steps of Renderer::iterate: double xstep = 1.0L / (double)width (main.cpp:352,355)
     s->xstep = (double)(1.0L / (long double)(double)s->width);
@@ -1435,6 +1467,11 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
     s->part.row_hi = s->height;
     int rc = setup_partition(s, 0, 1, 32, 8);
     if (rc == PT_OK) rc = upload_scene(s);
+    if (rc == PT_OK && s->estimator == PT_EST_BIDIR && !s->ds.nee_emission_only)
+        rc = fail(PT_ERR_UNSUPPORTED,
+                  "pt_scene_create: the bidirectional estimator is defined only where emission*colour of every light is zero "
+                  "(the reference scales that term by a value read past the end of flux_lookup, bidirectional.cpp:377-382,484), "
+                  "with no measured body, every glass ior >= 1 and finite, moderate numbers");
     if (rc != PT_OK) {
         pt_scene_destroy(s);
         return rc;
@@ -1609,6 +1646,8 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     const bool use_wavefront = uses_wavefront(s);
     if (!use_wavefront && (int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "the fused pipeline handles at most 127 bodies");
+    if (use_wavefront && s->estimator == PT_EST_BIDIR)
+        return fail(PT_ERR_UNSUPPORTED, "the bidirectional estimator runs the fused pipeline only");
     const int batch = use_wavefront ? s->wf_batch_alloc : s->batch_alloc;
     if (use_wavefront && (rc = ensure_wavefront_buffers(s))) return rc;
     const int nbatch = (n_iterations + batch - 1) / batch;
@@ -1658,14 +1697,8 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         if (use_wavefront) {
             int rcw = render_wavefront(s, st, it0, B, xs, ys, rs, npix, samples, J);
             if (rcw) return rcw;
-        } else if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
-            hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
-        else if (s->estimator == PT_EST_NEE && s->has_measured)
-            hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
-        else if (s->estimator == PT_EST_NEE)
-            hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
-        else
-            hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        } else
+            launch_trace(s, grid, st, P, it0, xs, ys, rs, npix, samples, J);
         HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], st));
         s->ev_used += 2;
         HIP_TRY(hipEventRecord(s->ev_trace[q], st));
@@ -1748,14 +1781,7 @@ int pt_render_device_noalloc(pt_scene* s, int first_iteration, int n_iterations,
         const int B = std::min(batch, left);
         launch_frame_layout(st, s->seed, W, H, it0, B, s->xstep, s->ystep, xs, ys, rs, npix, (int)(s->flags & PT_F_PIXEL_GRID));
         dim3 grid(P.owned_tiles, B);
-        if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
-            hipLaunchKernelGGL((k_trace<kEstNEE, false, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
-        else if (s->estimator == PT_EST_NEE && s->has_measured)
-            hipLaunchKernelGGL((k_trace<kEstNEE, true>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
-        else if (s->estimator == PT_EST_NEE)
-            hipLaunchKernelGGL((k_trace<kEstNEE, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
-        else
-            hipLaunchKernelGGL((k_trace<kEstPT, false>), grid, dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, samples, J);
+        launch_trace(s, grid, st, P, it0, xs, ys, rs, npix, samples, J);
         hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, st, P, W, H, B, npix, samples, J, accum_dev);
         HIP_TRY(hipGetLastError());
     }
@@ -1815,6 +1841,8 @@ int pt_trace_paths(pt_scene* s, const int32_t* it_idx2, const double* xy, int n,
     if (!s || !it_idx2 || !xy || n < 0) return fail(PT_ERR_INVALID, "pt_trace_paths: bad argument");
     if ((int)s->bodies.size() > kMaxBodiesFused)
         return fail(PT_ERR_UNSUPPORTED, "pt_trace_paths: per-path diagnostics run the fused estimator, at most 127 bodies");
+    if (s->estimator == PT_EST_BIDIR)
+        return fail(PT_ERR_UNSUPPORTED, "pt_trace_paths: no per-path diagnostics for the bidirectional estimator");
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(s->device));
     int rc = check_measured_tables(s);

@@ -16,7 +16,7 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
 REF_HOOKED_SO = os.path.join(ROOT, "oracle", "_ref", "libptref_hooked.so")
 
 MODE_SEQ, MODE_SCRIPT, MODE_PIXEL = 0, 1, 2
-EST_PT, EST_NEE = 0, 1
+EST_PT, EST_NEE, EST_BIDIR = 0, 1, 2  # EST_BIDIR: bidirectional.cpp:374-497
 SPHERE, PLANE, RECTANGLE, RECTANGLE_MT = 0, 1, 2, 3
 DIFFUSE, CHROME, GLASS, MEASURED = 0, 1, 2, 3
 RAND_MAX = 2147483647

@@ -1,0 +1,209 @@
+"""The bidirectional connection estimator (bidirectional.cpp:374-497).
+
+CPU: the C restatement against vectors the reference's own code produced
+(tests/golden/make_golden_bidir.py), and the preset against the scene the reference's main() builds.
+GPU: the HIP estimator through the C ABI against those vectors and against the restatement.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle
+import path_tracer_amd as pt
+from _oracle import EST_BIDIR, MODE_PIXEL
+from conftest import GOLDEN, ROOT, same_bits
+
+
+def golden():
+    with open(os.path.join(GOLDEN, "bidir.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLDEN, "bidir.npz"))
+
+
+def golden_scene_bodies(meta, z, key="scene_bodies"):
+    return _oracle.bodies_from_bytes(z[key], meta["body_record"])
+
+
+def test_flux_lookup_overrun_is_harmless():
+    """The reference reads flux_lookup past its end (bidirectional.cpp:377-382,484); its frames at -O0
+    and -O3, two processes each, are identical and finite (recorded by the golden generator)."""
+    with open(os.path.join(GOLDEN, "bidir_ub_check.json")) as f:
+        d = json.load(f)
+    assert d["frames_agree_and_finite"] and len(d["runs"]) == 4
+    assert len({r["sha256"] for r in d["runs"]}) == 1
+    assert {r["build"] for r in d["runs"]} == {"libptref.so", "libptref_O0.so"}
+
+
+def test_restatement_matches_reference_frames(port):
+    meta, z = golden()
+    bodies, n = golden_scene_bodies(meta, z)
+    cam = _oracle.camera_from_list(meta["camera"])
+    for c in meta["frames"]:
+        s = port.scene(bodies, n, cam, c["W"], c["H"], EST_BIDIR, seed=c["seed"])
+        got, draws = port.render(s, MODE_PIXEL, c["first"], c["n_it"])
+        assert same_bits(got, z["frame_" + c["key"]]), c["key"]
+        assert draws == c["draws"]
+    for c in meta["custom"]:
+        args, nb = golden_scene_bodies(meta, z, "custom_" + c["key"] + "_bodies")
+        stored = _oracle.constructed(port, args, nb)
+        s = port.scene(stored, nb, cam, c["W"], c["H"], EST_BIDIR, seed=c["seed"])
+        got, draws = port.render(s, MODE_PIXEL, c["first"], c["n_it"])
+        assert same_bits(got, z["custom_" + c["key"] + "_frame"]), c["key"]
+        assert draws == c["draws"]
+
+
+def test_preset_equals_reference_scene():
+    """bidir32 is the scene bidirectional.cpp's main() builds (:629-762), body for body."""
+    meta, z = golden()
+    want, n = golden_scene_bodies(meta, z)
+    d = pt.preset("bidir32", 8, 8)
+    assert d.body_count == n == 32 and d.estimator == pt.EST_BIDIR
+    for i in range(n):
+        b = pt.Body.from_buffer_copy(d.bodies[i])
+        pt.lib().pt_body_construct(C.byref(b))
+        for f in ("shape", "material"):
+            assert getattr(b, f) == getattr(want[i], f), (i, f)
+        for f in ("center", "color", "emission"):
+            assert list(getattr(b, f)) == list(getattr(want[i], f)), (i, f)
+        if b.shape == pt.PLANE:
+            assert list(b.normal) == list(want[i].normal), i
+        else:
+            assert b.radius == want[i].radius
+        if b.material == pt.GLASS:
+            assert (b.ior, b.reflection) == (want[i].ior, want[i].reflection)
+    cam = _oracle.camera_from_list(meta["camera"])
+    for f in ("origin", "topleft", "topright", "bottomleft"):
+        assert list(getattr(d.camera, f)) == list(getattr(cam, f))
+
+
+# ---- GPU ---------------------------------------------------------------------------------------
+
+def desc_from(bodies, n, W, H, seed, estimator=pt.EST_BIDIR, flags=0):
+    d = pt.preset("bidir32", W, H, seed=seed)
+    arr = (pt.Body * n)()
+    for i in range(n):
+        for f, _ in _oracle.Body._fields_:
+            setattr(arr[i], "reserved" if f == "pad" else f, getattr(bodies[i], f))
+    d.bodies = arr
+    d.body_count = n
+    d.estimator = estimator
+    d.flags = flags
+    d._keep = arr
+    return d
+
+
+def oracle_scene(port, r, W, H, seed, flags=0):
+    from test_gpu_parity import oracle_scene as f
+
+    return f(port, r, W, H, seed, flags=flags)
+
+
+@pytest.mark.gpu
+def test_gpu_golden_frames():
+    """Frames of the reference's own Renderer::iterate(), on its scene and on body lists built from
+    constructor arguments, bit for bit."""
+    meta, z = golden()
+    for c in meta["frames"]:
+        r = pt.Renderer(pt.preset("bidir32", c["W"], c["H"], seed=c["seed"]))
+        assert same_bits(r.render(c["first"], c["n_it"]), z["frame_" + c["key"]]), c["key"]
+        r.close()
+    for c in meta["custom"]:
+        args, nb = golden_scene_bodies(meta, z, "custom_" + c["key"] + "_bodies")
+        r = pt.Renderer(desc_from(args, nb, c["W"], c["H"], c["seed"]))
+        assert same_bits(r.render(c["first"], c["n_it"]), z["custom_" + c["key"] + "_frame"]), c["key"]
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,first,n_it,seed", [(64, 48, 0, 4, 1), (200, 3, 5, 2, 9), (1, 1, 0, 8, 3), (333, 201, 100, 1, 77)])
+def test_gpu_frames_match_oracle(port, W, H, first, n_it, seed):
+    r = pt.Renderer(pt.preset("bidir32", W, H, seed=seed))
+    want, _ = port.render(oracle_scene(port, r, W, H, seed), MODE_PIXEL, first, n_it)
+    assert same_bits(r.render(first, n_it), want)
+    # one call per iteration, and two tile partitions summed, give the same frame
+    acc = np.zeros((H, W, 3))
+    for it in range(first, first + n_it):
+        r.render(it, 1, acc)
+    assert same_bits(acc, want)
+    parts = np.zeros((H, W, 3))
+    for rank in range(2):
+        r.set_partition(rank, 2)
+        r.render(first, n_it, parts)
+    assert same_bits(parts, want)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_gpu_true_light_centre(port):
+    """PT_F_LIGHT_TRUE_CENTER: the light path starts at the light's own centre, where getNormal of a
+    sphere normalises a zero vector (NaN normal, the hemisphere flip never fires)."""
+    W, H, seed = 40, 30, 4
+    d = pt.preset("bidir32", W, H, seed=seed)
+    d.flags = pt.F_LIGHT_TRUE_CENTER
+    r = pt.Renderer(d)
+    want, _ = port.render(oracle_scene(port, r, W, H, seed, flags=pt.F_LIGHT_TRUE_CENTER), MODE_PIXEL, 0, 3)
+    assert same_bits(r.render(0, 3), want)
+    r.close()
+
+
+def random_dark_scene(seed, W, H):
+    """test_gpu_parity.random_scene with every light's colour forced to zero (the estimator's domain)."""
+    from test_gpu_parity import random_scene
+
+    d = random_scene(seed, W, H)
+    d.estimator = pt.EST_BIDIR
+    for i in range(d.body_count):
+        b = d.bodies[i]
+        if max(b.emission) >= 1.0:
+            for c in range(3):
+                b.color[c] = 0.0
+        if b.material == pt.GLASS and b.ior < 1.0:
+            b.ior = 2.0 - b.ior
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40, 56))
+def test_gpu_random_scenes_match_oracle(port, seed):
+    W, H = 32, 20
+    r = pt.Renderer(random_dark_scene(seed, W, H))
+    want, _ = port.render(oracle_scene(port, r, W, H, seed), MODE_PIXEL, 1, 2)
+    assert same_bits(r.render(1, 2), want)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_gpu_refuses_what_the_reference_leaves_undefined():
+    d = pt.preset("bidir32", 16, 16)
+    d.bodies[14].color[0] = 0.5  # a light with colour: its term would be scaled by the value past flux_lookup
+    with pytest.raises(pt.PtError, match="flux_lookup"):
+        pt.Renderer(d)
+    d = pt.preset("bidir32", 16, 16)
+    r = pt.Renderer(d)
+    r.set_pipeline(pt.PIPELINE_WAVEFRONT)
+    with pytest.raises(pt.PtError, match="fused pipeline only"):
+        r.render(0, 1)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_gpu_drop_in_executable(port, tmp_path):
+    """`bidirectional W H iterations threads`: next_event's worker split and save() around the estimator."""
+    W, H, iters, threads = 48, 20, 5, 2
+    exe = os.path.join(ROOT, "path_tracer_amd", "bin", "bidirectional")
+    out = str(tmp_path / "b.ppm")
+    subprocess.run([exe, str(W), str(H), str(iters), str(threads), "--seed", "6", "--out", out, "--quiet"], check=True, timeout=100)
+    r = pt.Renderer(pt.preset("bidir32", W, H, seed=6))
+    s = oracle_scene(port, r, W, H, 6)
+    r.close()
+    per = iters // threads
+    total = np.zeros((H, W, 3))
+    for k in range(threads):
+        priv, _ = port.render(s, MODE_PIXEL, k * per, per)
+        total = total + priv
+    with open(out, "rb") as f:
+        assert f.read() == port.save_ppm(total, iters, W, H)

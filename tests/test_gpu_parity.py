@@ -145,8 +145,8 @@ def test_golden_frames(port):
 
 @pytest.mark.parametrize("name,W,H,n_it", [("nee15", 96, 64, 6), ("main32", 80, 48, 5), ("nee15", 33, 7, 40),
                                            ("nee15_lit", 64, 40, 5), ("pt15", 40, 40, 4), ("bipath23", 72, 40, 4), ("nee32", 50, 30, 4),
-                                           # the headline frame size, a few iterations of it
-                                           ("nee15", 1024, 768, 3), ("main32", 1024, 768, 3)])
+                                           # the headline frame size: sixteen iterations of it (20 s of oracle time)
+                                           ("nee15", 1024, 768, 16), ("main32", 1024, 768, 3)])
 def test_frames_match_oracle(port, name, W, H, n_it):
     r = pt.Renderer(pt.preset(name, W, H, seed=2025))
     s = oracle_scene(port, r, W, H, 2025)
@@ -893,6 +893,15 @@ def test_rectangles_in_the_wavefront_pipeline(port, seed):
     r.close()
 
 
+def free_port():
+    """A TCP port nobody listens on right now (two sessions sharing a box must not pick the same one)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
+
+
 def test_two_ranks_share_one_gpu():
     """Two ranks (gloo, both on cuda:0) render their tile partitions concurrently and all-reduce; the
     reduced frame equals the single-partition frame bit for bit.  Concurrent processes stretch the gaps
@@ -902,7 +911,7 @@ def test_two_ranks_share_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PTGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "--master-addr", "127.0.0.1", "--master-port", free_port(),
            os.path.join(root, "scripts", "rehearse_ranks.py"), "60"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -948,7 +957,7 @@ def test_rccl_exchange_with_one_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PTGPU_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0",
+    env = dict(os.environ, PTGPU_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "rehearse_ranks.py"), "40"], env=env,
                          capture_output=True, text=True, timeout=110)

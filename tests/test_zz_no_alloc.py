@@ -52,3 +52,33 @@ def test_noalloc_render_rejects_what_does_not_fit():
     with pytest.raises(pt.PtError, match="fused"):
         r.render_device_noalloc(0, 1, b.data_ptr(), 0)
     r.close()
+
+
+def test_noalloc_render_under_graph_capture():
+    """The callers the entry point is for: the whole call is recorded into a HIP graph (capture mode
+    "global", under which any hipMalloc, hipFree or synchronising call fails and invalidates the
+    capture) and the replayed graph gives the bits of pt_render_device."""
+    import torch
+
+    W, H, first, n_it = 160, 90, 3, 11
+    r = pt.Renderer(pt.preset("nee15", W, H, seed=8))
+    want = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    r.render_device(first, n_it, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    warm = torch.zeros_like(want)
+    r.render_device_noalloc(first, 1, warm.data_ptr(), torch.cuda.current_stream().cuda_stream)  # resolves the scratch address
+    torch.cuda.synchronize()
+    got = torch.zeros_like(want)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="global"):
+        r.render_device_noalloc(first, n_it, got.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert float(got.abs().sum()) == 0.0  # nothing ran during capture
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+    got.zero_()
+    graph.replay()  # the scratch keeps the first replay's contents; the second must not care
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+    r.close()
