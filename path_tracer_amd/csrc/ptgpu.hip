@@ -187,13 +187,13 @@ void launch_frame_layout(hipStream_t st, uint64_t seed, int W, int H, int first_
 // keeps four positions per path in LDS (26 368 B per block) and fits 80 VGPRs: six blocks per CU.
 // The path-tracing kernel keeps no positions and fits 64 VGPRs: eight.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : EST == kEstNEE ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
     // path tracing keeps no vertex positions; the compact next-event form keeps the deepest vertex's in
     // registers (see trace_path_nee_compact), which lets a sixth block share the CU's LDS
-    __shared__ double s_pts[EST == kEstPT ? 1 : (COMPACT ? kMaxDepth - 1 : kMaxDepth) * 3 * kBlock];
+    __shared__ double s_pts[EST == kEstPT ? 1 : (EST == kEstNEE ? kMaxDepth - 1 : kMaxDepth) * 3 * kBlock];
     __shared__ int8_t s_bod[kMaxDepth * kBlock];
     __shared__ uint16_t s_slots[COMPACT ? kBlock : 1];
     const int tid = threadIdx.x;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
     } else if (EST == kEstBidir) {
         if (valid) rgb = trace_path_bidir(S, dr, x, y, rec);
     } else if (valid) {
-        PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
+        PathResult R = trace_path<EST, MEASURED, true, EST == kEstNEE>(S, dr, x, y, rec);
         rgb = R.rgb;
     }
 #ifdef PT_PROFILE_SECTIONS
@@ -745,6 +745,14 @@ struct SceneUpload {
     // A slab joins, per axis, the two axis-aligned planes with the smallest and the largest
     // coordinate, provided the bound slab_big is usable.
     void find_slabs() {
+        // An axis without a slab holds an empty interval and no bodies: scan_slab on it — which a scan could
+        // reach through a stale loop guard, see scan_lists — forms infinite quotients that win nothing.
+        for (int axis = 0; axis < 3; ++axis) {
+            D.slab_lo[axis] = INFINITY;
+            D.slab_hi[axis] = -INFINITY;
+            D.slab_big[axis] = 0.0;
+            D.slab_ilo[axis] = D.slab_ihi[axis] = -1;
+        }
         for (int axis = 0; axis < 3 && hit_eps == 0.0; ++axis) {  // the slab form assumes the threshold t > 0
             int lo = -1, hi = -1;
             auto coord = [&](int i) { return axis == 0 ? geom[i].cx : axis == 1 ? geom[i].cy : geom[i].cz; };
@@ -781,10 +789,13 @@ struct SceneUpload {
             }
         }
         // Neither list is ever empty: an empty one gets records that can never be hit, so that the scan
-        // loops always have a first iteration.  (The compiler turns `for (k < n)` into a guard and a
-        // count-down loop and may keep the guard, a wave-uniform boolean, as a lane mask taken while only
-        // some lanes were active; a later scan by other lanes then reads it as "n > 0" and would enter the
-        // loop with a count of zero.  Seen in the bidirectional kernel on a scene without planes.)
+        // loops always have a first iteration.  The compiler turns `for (k < n)` into a guard and a
+        // count-down loop, and under register pressure it keeps a wave-uniform boolean such as that guard
+        // in a vector register and reads it back as a lane mask of the lanes active at that moment; a
+        // later scan run by other lanes of the wave (lanes that had left the first loop early) then sees
+        // "n > 0" and enters the loop with a count of zero.  Seen in the bidirectional kernel, whose light
+        // path can be walked by lanes whose gather path ended at once, on a scene without planes.  The
+        // same goes for the slab bits of DScene::slab_mask, hence the harmless defaults in find_slabs.
         if (scan_planes.empty()) {
             DGeom g;
             memset(&g, 0, sizeof g);
