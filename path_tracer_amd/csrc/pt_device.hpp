@@ -1327,12 +1327,9 @@ PTD_INLINE V3 nee_vertex(const DScene& S, const DGeom& g, const DMat& m, Draws& 
 //  PT : Renderer::trace main.cpp:367-405 — the recursion `trace(next)*color + emission` is a Horner
 //       evaluation from the deepest hit outwards.
 //  NEE: pixel body of Renderer::iterate next_event.cpp:384-470 with trace() next_event.cpp:491-530.
-// DEEP_REG: the LDS records hold kMaxDepth - 1 positions and the deepest vertex's stays in registers
-// (it is read back once, by the first round of the next-event loop), so that six blocks share a CU's LDS.
-template <int EST, bool MEASURED, bool ELIDE, bool DEEP_REG = false>
+template <int EST, bool MEASURED, bool ELIDE>
 PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y, const Records& rec,
                                  int* brdf_ind = nullptr) {
-    V3 p_last = mk(0.0, 0.0, 0.0);
     const DGeom* __restrict__ geom = S.geom;
     const DMat* __restrict__ mat = S.mat;
     V3 o = ld3(S.cam_o);
@@ -1348,10 +1345,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         PT_PROF(kProfRecords);
         if (EST == kEstPT && ELIDE)
             rec.put_body(n, hit);  // plain path tracing reads only the bodies back (the render kernel keeps no points)
-        else if (DEEP_REG && n == kMaxDepth - 1) {
-            rec.put_body(n, hit);  // the records hold kMaxDepth - 1 positions: the deepest vertex keeps its own
-            p_last = point;
-        } else
+        else
             rec.put(n, point, hit);
     }
     PathResult R;
@@ -1377,8 +1371,7 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         int target;
         {
             PT_PROF(kProfNeePrep);
-            P = rec.point(DEEP_REG && gi == kMaxDepth - 1 ? 0 : gi);
-            if (DEEP_REG && gi == kMaxDepth - 1) P = p_last;
+            P = rec.point(gi);
             target = rec.body(gi);
             lc = light_origin(S, light);
             bd = normalize(sub(P, lc));

@@ -187,13 +187,13 @@ void launch_frame_layout(hipStream_t st, uint64_t seed, int W, int H, int first_
 // keeps four positions per path in LDS (26 368 B per block) and fits 80 VGPRs: six blocks per CU.
 // The path-tracing kernel keeps no positions and fits 64 VGPRs: eight.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : EST == kEstNEE ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
     // path tracing keeps no vertex positions; the compact next-event form keeps the deepest vertex's in
     // registers (see trace_path_nee_compact), which lets a sixth block share the CU's LDS
-    __shared__ double s_pts[EST == kEstPT ? 1 : (EST == kEstNEE ? kMaxDepth - 1 : kMaxDepth) * 3 * kBlock];
+    __shared__ double s_pts[EST == kEstPT ? 1 : (COMPACT ? kMaxDepth - 1 : kMaxDepth) * 3 * kBlock];
     __shared__ int8_t s_bod[kMaxDepth * kBlock];
     __shared__ uint16_t s_slots[COMPACT ? kBlock : 1];
     const int tid = threadIdx.x;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : EST == kEstNEE ? 6
     } else if (EST == kEstBidir) {
         if (valid) rgb = trace_path_bidir(S, dr, x, y, rec);
     } else if (valid) {
-        PathResult R = trace_path<EST, MEASURED, true, EST == kEstNEE>(S, dr, x, y, rec);
+        PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
         rgb = R.rgb;
     }
 #ifdef PT_PROFILE_SECTIONS
