@@ -18,4 +18,5 @@ run p2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ
 run p3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_IFETCH &&
 run p4 GRBM_GUI_ACTIVE FETCH_SIZE &&
 run p5 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum &&
+run p6 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum &&
 python3 scripts/pmc_report.py $out
