@@ -234,9 +234,14 @@ def main():
         lights = [i for i in range(desc.body_count) if max(desc.bodies[i].emission) >= 1.0]
         flop_per_path += 5.0 * (scan - (19.0 if desc.bodies[lights[-1]].shape == pt.SPHERE else 14.0))
         rays_per_path = 10
+    if desc.estimator == pt.EST_BIDIR:
+        # bidirectional.cpp:394-437: five gather scans, five light-path scans, and one scan per (gather vertex,
+        # light-path vertex) pair with the chosen light (a sphere in every draw of the shipped scene) left out
+        flop_per_path = 10.0 * scan + 25.0 * (scan - 19.0)
+        rays_per_path = 35
     wavefront = args.pipeline == "wavefront" or (args.pipeline != "fused" and desc.body_count > 127)
     kernel_name = "k_wf_* stages (wavefront pipeline)" if wavefront else (
-        "k_trace<NEE>" if desc.estimator == pt.EST_NEE else "k_trace<PT>")
+        "k_trace<NEE>" if desc.estimator == pt.EST_NEE else "k_trace<BIDIR>" if desc.estimator == pt.EST_BIDIR else "k_trace<PT>")
     accum = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     exchange = ptdist.Exchange(r, world, accum.device) if args.exchange == "gather" else None

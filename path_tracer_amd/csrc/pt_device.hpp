@@ -22,11 +22,16 @@ namespace ptd {
 #ifdef PT_PROFILE_SECTIONS
 enum {
     kProfTotal, kProfSetup, kProfScanPlanes, kProfScanScreen, kProfScanExact, kProfShade, kProfGlass, kProfDiffuse,
-    kProfChrome, kProfNormalSphere, kProfNeePrep, kProfNeeVertex, kProfRecords, kProfN
+    kProfChrome, kProfNormalSphere, kProfNeePrep, kProfNeeVertex, kProfRecords,
+    kProfRejectTrips,  // not a time: trips of the hemisphere rejection loop per wave (slot k) and per lane (slot kProfN + k)
+    kProfN
 };
 constexpr int kProfWaves = 4;
-__shared__ long long s_prof[kProfWaves * kProfN];
-__device__ unsigned long long g_prof[kProfN];
+// per wave: slot k = cycles of section k, slot kProfN + k = the same cycles times the lanes active
+// when the section ended (lanes that take part in the section; loops inside may run with fewer)
+constexpr int kProfSlots = 2 * kProfN;
+__shared__ long long s_prof[kProfWaves * kProfSlots];
+__device__ unsigned long long g_prof[kProfSlots];
 struct ProfScope {
     int k;
     long long t0;
@@ -35,15 +40,30 @@ struct ProfScope {
         long long dt = (long long)__builtin_amdgcn_s_memtime() - t0;
         unsigned long long act = __builtin_amdgcn_ballot_w64(true);
         int lane = (int)(threadIdx.x & 63);
-        if (lane == __builtin_ctzll(act)) s_prof[(threadIdx.x >> 6) * kProfN + k] += dt;
+        if (lane == __builtin_ctzll(act)) {
+            s_prof[(threadIdx.x >> 6) * kProfSlots + k] += dt;
+            s_prof[(threadIdx.x >> 6) * kProfSlots + kProfN + k] += dt * (long long)__builtin_popcountll(act);
+        }
     }
 };
+// one trip of a loop that lanes leave one by one: counted once per wave and once per active lane
+PTD_INLINE void prof_trip(int k) {
+    unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) {
+        s_prof[(threadIdx.x >> 6) * kProfSlots + k] += 1;
+        s_prof[(threadIdx.x >> 6) * kProfSlots + kProfN + k] += (long long)__builtin_popcountll(act);
+    }
+}
+#define PT_PROF_TRIP(k) prof_trip(k)
 #define PT_PROF_CAT2(a, b) a##b
 #define PT_PROF_CAT(a, b) PT_PROF_CAT2(a, b)
 #define PT_PROF(k) ProfScope PT_PROF_CAT(prof_scope_, __LINE__)(k)
 #else
 #define PT_PROF(k) \
     do {           \
+    } while (0)
+#define PT_PROF_TRIP(k) \
+    do {                \
     } while (0)
 #endif
 
@@ -335,6 +355,17 @@ PTD_INLINE T load_record(const T* p) {
 #pragma unroll
     for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
     return out;
+}
+
+// The wave-uniform controls of the scan (list lengths, slab bits, the shadow-origin flag) as fresh
+// scalar values.  An estimator runs its scans in phases — the gather loop, then the loop over shadow
+// or light-path rays — and lanes that leave the first phase early come back for the second.  The
+// compiler may park a uniform boolean such as "the scene has an x slab" in a vector register and read
+// it back, inside the first loop, as a mask of the lanes active there; reused by the second phase it
+// is wrong for the lanes that had left.  Values that pass through this barrier cannot be traced back
+// to the ones the first phase tested, so the second phase derives its controls anew.
+PTD_INLINE void refresh_scan_controls(DScene& S) {
+    asm volatile("" : "+s"(S.n_planes), "+s"(S.n_spheres), "+s"(S.slab_mask), "+s"(S.flags));
 }
 
 // Camera::getPoint next_event.cpp:159-161: topleft.add(xd.muls(x)).add(yd.muls(y))
@@ -848,6 +879,7 @@ PTD_INLINE uint32_t rng_next_sum_flipped(Rng& r) {  // rng_next_sum + 2^31 (mod 
 PTD_INLINE V3 random_in_hemisphere(Draws& dr, V3 n) {
     uint32_t tz, ty, tx;  // flipped sums
     for (;;) {
+        PT_PROF_TRIP(kProfRejectTrips);
         tz = rng_next_sum_flipped(dr.rng);
         ty = rng_next_sum_flipped(dr.rng);
         tx = rng_next_sum_flipped(dr.rng);
@@ -1365,6 +1397,8 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
         return R;
     }
     const int light = pick_light(S, dr);
+    DScene T = S;  // the second phase: see refresh_scan_controls
+    refresh_scan_controls(T);
 #pragma unroll 1
     for (int gi = n - 1; gi >= 0; --gi) {
         V3 P, bd, lc;
@@ -1373,11 +1407,11 @@ PTD_INLINE PathResult trace_path(const DScene& S, Draws& dr, double x, double y,
             PT_PROF(kProfNeePrep);
             P = rec.point(gi);
             target = rec.body(gi);
-            lc = light_origin(S, light);
+            lc = light_origin(T, light);
             bd = normalize(sub(P, lc));
         }
         double mint;
-        int hit = nearest_hit_shadow(S, lc, bd, light, mint);
+        int hit = nearest_hit_shadow(T, lc, bd, light, mint);
         if (hit != target) continue;  // occluded: the vertex is skipped entirely, next_event.cpp:428-430
         R.visible |= 1 << gi;
         PT_PROF(kProfNeeVertex);
@@ -1442,6 +1476,8 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
     }
     const int lane = rec.tid & 63;
     const int wave_tid0 = rec.tid & ~63;
+    DScene T = S;  // the second phase: see refresh_scan_controls
+    refresh_scan_controls(T);
     // An absorbing emitter (colour exactly 0) that is lit sets L to its emission whatever the deeper
     // vertices gave — (L + 0) * 0 + e with L finite — so the deeper shadow scans are needed only when that
     // vertex turns out to be in shadow (0.15 % of them in the reference's room), or when a deeper twin
@@ -1508,11 +1544,11 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
                 PT_PROF(kProfNeePrep);
                 P = rec.point_of(g < kMaxDepth - 1 ? g : 0, owner);
                 if (g == kMaxDepth - 1) P = p_deep;
-                lc = light_origin(S, lt);
+                lc = light_origin(T, lt);
                 bd = normalize(sub(P, lc));  // next_event.cpp:405-407
             }
             double mint;
-            int hit = nearest_hit_shadow(S, lc, bd, lt, mint);
+            int hit = nearest_hit_shadow(T, lc, bd, lt, mint);
             lit = hit == rec.body_of(g, owner);  // next_event.cpp:428-430
         }
         const lanemask lit_mask = PTD_MASK(lit);
@@ -1583,17 +1619,19 @@ PTD_INLINE V3 trace_path_bidir(const DScene& S, Draws& dr, double x, double y, c
     o = light_origin(S, light);
     d = random_in_hemisphere(dr, shape_normal(S.geom[light], o));
     unsigned seen = 0;  // three bits per gather vertex: the number of light-path vertices that see it
+    DScene T = S;  // the second phase: see refresh_scan_controls
+    refresh_scan_controls(T);
 #pragma unroll 1
     for (int ns = 0; ns < kMaxDepth; ++ns) {
         double mint;
-        int hit = nearest_hit_any(S, o, d, mint);
+        int hit = nearest_hit_any(T, o, d, mint);
         if (hit < 0) break;
         const V3 sp = shade_hit(S.geom[hit], S.mat[hit], dr, o, d, mint);
 #pragma unroll 1
         for (int g = 0; g < need; ++g) {
             const V3 bd = normalize(sub(rec.point(g), sp));  // bi_ray :415-417
             double t;
-            const int h = nearest_hit<false>(S, sp, bd, light, t);
+            const int h = nearest_hit<false>(T, sp, bd, light, t);
             seen += (h == rec.body(g) ? 1u : 0u) << (3 * g);  // :435-437
         }
     }

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
     double* out = samples + (size_t)b * 3 * sample_stride + j;
     V3 rgb = mk(0.0, 0.0, 0.0);
 #ifdef PT_PROFILE_SECTIONS
-    if (tid < kProfWaves * kProfN) s_prof[tid] = 0;
+    if (tid < kProfWaves * kProfSlots) s_prof[tid] = 0;
     __syncthreads();
     {
     PT_PROF(kProfTotal);
@@ -235,8 +235,12 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
         y = ys[(size_t)b * H + r];
         dr.rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
 #ifdef PT_PROFILE_SECTIONS
-        if ((tid & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
-            s_prof[(tid >> 6) * kProfN + kProfSetup] += (long long)__builtin_amdgcn_s_memtime() - t_setup;
+        const unsigned long long act_setup = __builtin_amdgcn_ballot_w64(true);
+        if ((tid & 63) == __builtin_ctzll(act_setup)) {
+            const long long dt = (long long)__builtin_amdgcn_s_memtime() - t_setup;
+            s_prof[(tid >> 6) * kProfSlots + kProfSetup] += dt;
+            s_prof[(tid >> 6) * kProfSlots + kProfN + kProfSetup] += dt * (long long)__builtin_popcountll(act_setup);
+        }
 #endif
     }
     Records rec;
@@ -255,7 +259,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
 #ifdef PT_PROFILE_SECTIONS
     }
     __syncthreads();
-    if (tid < kProfWaves * kProfN) atomicAdd(&g_prof[tid % kProfN], (unsigned long long)s_prof[tid]);
+    if (tid < kProfWaves * kProfSlots) atomicAdd(&g_prof[tid % kProfSlots], (unsigned long long)s_prof[tid]);
 #endif
     rgb = canonical_nan(rgb);
     out[0] = rgb.x;
@@ -2036,12 +2040,13 @@ extern "C" int pt_scan_stats(unsigned long long* out) {
 #endif
 
 #ifdef PT_PROFILE_SECTIONS
-// Development only: cycles per section summed over waves since the last call (and reset).
+// Development only: per section, cycles summed over waves and cycles times active lanes, since the
+// last call (and reset): out[k] and out[kProfN + k].  Returns kProfN.
 extern "C" int pt_prof_read(unsigned long long* out, int n) {
-    unsigned long long h[ptd::kProfN] = {};
+    unsigned long long h[ptd::kProfSlots] = {};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ptd::g_prof), sizeof h) != hipSuccess) return -1;
-    for (int k = 0; k < n && k < ptd::kProfN; ++k) out[k] = h[k];
-    unsigned long long z[ptd::kProfN] = {};
+    for (int k = 0; k < n && k < ptd::kProfSlots; ++k) out[k] = h[k];
+    unsigned long long z[ptd::kProfSlots] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_prof), z, sizeof z) != hipSuccess) return -1;
     return ptd::kProfN;
 }
