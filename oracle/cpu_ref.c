@@ -4,9 +4,14 @@
  * /root/reference/main.cpp (plain path tracing), /root/reference/next_event.cpp (path
  * tracing + next-event estimation) and /root/reference/bidirectional.cpp (gather path x light
  * path connections), plus /root/reference/MatusikBRDF.h (measured BRDF lookup).
- * Every function cites the reference lines it follows.  It is pinned against the reference's
- * own code compiled here (oracle/_ref, see oracle/Makefile and tests/test_oracle_vs_ref.py)
- * and against the golden vectors under tests/golden/ generated from it.
+ * Every function cites the reference lines it follows.  It is pinned against the golden vectors
+ * under tests/golden/, which the reference's own code produced: oracle/_ref, the reference's
+ * programs compiled here without Boost and without a stand-in for it (the lines of thread glue are
+ * left out, nothing is put in their place; oracle/Makefile, tests/test_reference_build.py), driven by
+ * the generator scripts tests/golden/make_golden*.py.  Not pinned, for want of anything to pin them
+ * to: values of real MERL tables (the .binary files are absent from the reference checkout) and the
+ * Moller-Trumbore rectangle and row split of light_tracing.cpp (every program that holds them
+ * includes kdtree.h, which the checkout lacks): "parity unpinned" for those two.
  *
  * Floating point: the reference is x86-64 g++ code — IEEE double with SSE2, no FMA
  * contraction, and x87 80-bit arithmetic wherever an `L` literal makes an expression

@@ -11,6 +11,18 @@ enum {
 };
 
 #ifdef __cplusplus
+/* How the harness borrows the Scene that a reference program's main() builds on its stack: the
+ * program's own call `save(buffer, iterations, width, height)` at the end of main() is compiled, for
+ * main() only, as a call of ptor::scene_hook(&scene) (a macro set between the definition of save() and
+ * main(); see ref_harness.cpp). */
+namespace ptor {
+typedef void (*scene_hook_fn)(void* scene);
+extern scene_hook_fn scene_hook_target;
+inline void scene_hook(void* scene) {
+    if (scene_hook_target) scene_hook_target(scene);
+}
+}  // namespace ptor
+
 extern "C" {
 #endif
 void ptor_rt_register(int prog, void* getray, void* iadd);

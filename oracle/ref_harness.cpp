@@ -1,11 +1,17 @@
-// TEST INFRASTRUCTURE ONLY — harness around the UNMODIFIED reference sources.
+// TEST INFRASTRUCTURE ONLY — harness around the reference's own sources.
 //
-// The reference programs (main.cpp, next_event.cpp, raytrace3.cpp, bidirectional.cpp) are textually included (from where they lie under the
-// reference checkout; nothing is copied) into separate namespaces, with `main` renamed by
-// the preprocessor.  The scene each program builds on the stack of its main()
-// (/root/reference/main.cpp:473-607, next_event.cpp:605-689) is borrowed through the boost
-// shim's thread-launch hook, so scene constants are never restated here.  All randomness
-// comes from the linker-wrapped rand() in ref_rt.cpp.
+// The reference programs (main.cpp, next_event.cpp, raytrace3.cpp, bidirectional.cpp) need Boost only
+// for their thread glue: four #include lines, one global mutex, the lock in worker() and the
+// thread spawn / join / delete statements of main().  The image has no Boost, and nothing stands in
+// for it: oracle/Makefile writes, at build time and outside the repository's history, a copy of each
+// program from which exactly the lines that mention `boost` or `threads` are left out
+// (grep -v -E 'boost|threads'), cut in two at `int main(`.  Every remaining line is the reference's,
+// in the reference's order; what is left out is the threading, which this build replaces anyway.
+// The two parts are textually included here into one namespace per program, with `main` renamed.
+// Between them a macro turns the one call of save() inside main() into ptor::scene_hook(&scene):
+// that is how the scene each program builds on the stack of its main()
+// (/root/reference/main.cpp:473-607, next_event.cpp:605-689, ...) is borrowed, so scene constants are
+// never restated here.  All randomness comes from the linker-wrapped rand() in ref_rt.cpp.
 //
 // Build recipe: oracle/Makefile (outputs only under oracle/_ref/).
 #include <algorithm>
@@ -27,39 +33,53 @@
 
 #include "ptor_rt.h"
 #include "ptor_types.h"
-#include "shim/ptor_boost_shim.hpp"
 
-#ifndef PTOR_REF_MAIN
-#error "define PTOR_REF_MAIN / PTOR_REF_NEE / PTOR_REF_RT3 / PTOR_REF_BIDIR / PTOR_REF_BRDF as quoted paths into the reference checkout"
+#ifndef PTOR_REF_MAIN_A
+#error "define PTOR_REF_<MAIN|NEE|RT3|BIDIR>_<A|B> (the two parts of each program, see oracle/Makefile) and PTOR_REF_BRDF"
 #endif
 
+// inside main() only: save(buffer, iterations, width, height) -> the harness's scene hook
+#define PTOR_SAVE_AS_HOOK(b, s, w, h) ptor::scene_hook((void*)&scene)
+
 namespace ref_pt {
+#include PTOR_REF_MAIN_A
+#define save PTOR_SAVE_AS_HOOK
 #define main ref_main
-#include PTOR_REF_MAIN
+#include PTOR_REF_MAIN_B
 #undef main
+#undef save
 }  // namespace ref_pt
 
 namespace ref_nee {
+#include PTOR_REF_NEE_A
+#define save PTOR_SAVE_AS_HOOK
 #define main ref_main
-#include PTOR_REF_NEE
+#include PTOR_REF_NEE_B
 #undef main
+#undef save
 }  // namespace ref_nee
 
 // raytrace3.cpp: main.cpp's estimator with a hit threshold of 1e-7 and a third shape, Rectangle
 // (raytrace3.cpp:244-330, :761-851).  It includes MatusikBRDF.h itself, hence the guard reset below.
 // Built with -fno-access-control: Rectangle's corner points are private members.
 namespace ref_rt3 {
+#include PTOR_REF_RT3_A
+#define save PTOR_SAVE_AS_HOOK
 #define main ref_main
-#include PTOR_REF_RT3
+#include PTOR_REF_RT3_B
 #undef main
+#undef save
 }  // namespace ref_rt3
 
 // bidirectional.cpp: next_event.cpp's gather path plus a light sub-path and the gather x shoot
 // connection loop (bidirectional.cpp:374-497), on its own 32-body scene (:683-762).
 namespace ref_bidir {
+#include PTOR_REF_BIDIR_A
+#define save PTOR_SAVE_AS_HOOK
 #define main ref_main
-#include PTOR_REF_BIDIR
+#include PTOR_REF_BIDIR_B
 #undef main
+#undef save
 }  // namespace ref_bidir
 
 #undef _MATUSIKBRDFREADER_H_
@@ -184,9 +204,8 @@ RT3::Shape* make_rectangle<RT3>(const ptor_body& b) {
 std::function<void(void*)> g_session;
 std::string g_scratch = "/tmp";
 
-bool session_hook(const ptor::Launch& l) {
-    if (g_session) g_session(l.scene);
-    return true;  // never run the reference worker from a session
+void session_hook(void* scene) {
+    if (g_session) g_session(scene);
 }
 
 struct CoutSilencer {
@@ -226,11 +245,11 @@ void with_scene(const std::function<void(typename T::Scene*)>& fn) {
     CoutSilencer quiet;
     ChdirScratch cd;
     g_session = [&](void* s) { fn((typename T::Scene*)s); };
-    ptor::thread_hook = &session_hook;
+    ptor::scene_hook_target = &session_hook;
     const char* argv[] = {"ref", "2", "2", "1", "1"};
-    ptor_rt_mode_seq(1, 0);  // main()'s own save() etc. draw nothing, but keep the wrap defined
+    ptor_rt_mode_seq(1, 0);  // main() draws nothing, but keep the wrap defined
     T::run_main(5, argv);
-    ptor::thread_hook = 0;
+    ptor::scene_hook_target = 0;
     g_session = nullptr;
 }
 

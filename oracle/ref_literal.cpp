@@ -6,10 +6,6 @@
 // from the source where it lies; outputs only under oracle/_ref/.
 #include "shim/ptor_boost_shim.hpp"
 
-namespace ptor {
-thread_hook_fn thread_hook = 0;  // no harness: every worker runs
-}
-
 #ifndef PTOR_REF_NEE
 #error "define PTOR_REF_NEE as the quoted path of next_event.cpp in the reference checkout"
 #endif

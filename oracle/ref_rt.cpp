@@ -10,12 +10,11 @@
 
 #include "ptor_rng.h"
 #include "ptor_rt.h"
-#include "shim/ptor_boost_shim.hpp"
 
 #define PTOR_NOINST __attribute__((no_instrument_function))
 
 namespace ptor {
-thread_hook_fn thread_hook = 0;
+scene_hook_fn scene_hook_target = 0;
 }
 
 namespace {

@@ -1,24 +1,14 @@
-// TEST INFRASTRUCTURE ONLY (oracle build). Minimal boost -> std mapping so that the
-// reference translation units compile unmodified in a container without Boost.
-// Covers exactly what /root/reference/main.cpp:7-13,444,642-654 and
-// /root/reference/next_event.cpp:6-13,564,701-708 use: boost::mutex,
-// boost::mutex::scoped_lock, boost::bind(&worker, int, n, Scene*, V3*), boost::thread(ctor, join).
-// A launch hook lets the harness borrow the Scene that the reference's main() builds on its stack.
+// TEST INFRASTRUCTURE ONLY.  Minimal boost -> std mapping: boost::mutex, boost::mutex::scoped_lock,
+// boost::bind(&worker, int, n, Scene*, V3*), boost::thread(ctor, join), i.e. what
+// /root/reference/main.cpp:7-13,444,642-654 and next_event.cpp:6-13,564,701-708 use.
+// NOT part of the parity oracle: the reference builds that produce golden vectors and check the
+// restatement (oracle/_ref/libptref*.so) contain no Boost and no stand-in for it (oracle/Makefile).
+// Two things still read the reference with its thread glue and therefore go through this header:
+// the literal multi-threaded next_event run that is only ever timed (ref_literal.cpp), and the
+// syntax check of the binding stub a maintainer with Boost would add (binding_stub_check.cpp).
 #pragma once
 #include <mutex>
 #include <thread>
-
-namespace ptor {
-struct Launch {
-    int worker;
-    int iterations;
-    void* scene;
-    void* buffer;
-};
-// Return true when the launch was consumed by the harness (the worker is then NOT run).
-typedef bool (*thread_hook_fn)(const Launch&);
-extern thread_hook_fn thread_hook;
-}  // namespace ptor
 
 namespace boost {
 
@@ -48,11 +38,7 @@ class thread {
 
 public:
     template <class S, class B>
-    explicit thread(ptor_bound4<S, B> b) {
-        ptor::Launch l = {b.a, b.b, (void*)b.s, (void*)b.buf};
-        if (ptor::thread_hook && ptor::thread_hook(l)) return;
-        t_ = std::thread(b);
-    }
+    explicit thread(ptor_bound4<S, B> b) : t_(b) {}
     void join() {
         if (t_.joinable()) t_.join();
     }
