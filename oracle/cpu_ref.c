@@ -8,10 +8,12 @@
  * under tests/golden/, which the reference's own code produced: oracle/_ref, the reference's
  * programs compiled here without Boost and without a stand-in for it (the lines of thread glue are
  * left out, nothing is put in their place; oracle/Makefile, tests/test_reference_build.py), driven by
- * the generator scripts tests/golden/make_golden*.py.  Not pinned, for want of anything to pin them
- * to: values of real MERL tables (the .binary files are absent from the reference checkout) and the
- * Moller-Trumbore rectangle and row split of light_tracing.cpp (every program that holds them
- * includes kdtree.h, which the checkout lacks): "parity unpinned" for those two.
+ * the generator scripts tests/golden/make_golden*.py.  That includes the Moller-Trumbore Rectangle of
+ * light_tracing.cpp, whose class compiles from the head of that file although the program does not
+ * (kdtree.h is absent).  Not pinned, for want of anything to pin them to: values of real MERL tables
+ * (the .binary files are absent from the reference checkout), and the row range / row split of
+ * light_tracing.cpp (inside its photon-map Renderer and main(), which need the kd-tree): "parity
+ * unpinned" for those two, which closed-form known answers cover instead.
  *
  * Floating point: the reference is x86-64 g++ code — IEEE double with SSE2, no FMA
  * contraction, and x87 80-bit arithmetic wherever an `L` literal makes an expression

@@ -24,6 +24,7 @@
 #include <ctime>
 #include <fstream>
 #include <functional>
+#include <queue>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -81,6 +82,13 @@ namespace ref_bidir {
 #undef main
 #undef save
 }  // namespace ref_bidir
+
+// light_tracing.cpp up to `struct Scene`: its vector, ray, shape and material classes, of which the
+// Moller-Trumbore Rectangle (light_tracing.cpp:477-575) is the one no other program has.  The rest of
+// that file needs kdtree.h, which is absent.
+namespace ref_lt {
+#include PTOR_REF_LT_HEAD
+}  // namespace ref_lt
 
 #undef _MATUSIKBRDFREADER_H_
 namespace ref_brdf {
@@ -556,6 +564,20 @@ int ptor_brdf_lookup(const char* file, const double* angles4, int n, double* rgb
     for (int i = 0; i < n; i++) {
         const double* a = angles4 + 4 * i;
         brdf.lookup_brdf_val(a[0], a[1], a[2], a[3], rgb_out[3 * i], rgb_out[3 * i + 1], rgb_out[3 * i + 2]);
+    }
+    return 0;
+}
+
+// light_tracing.cpp's Rectangle(p1, p2, p3, p4) (:484-495) built from corners12, its stored normal, and
+// Rectangle::intersect (:503-575) for n rays: t_out[n].
+int ptor_lt_rectangle(const double* corners12, const double* rays6, int n, double* t_out, double* normal3_out) {
+    const double* c = corners12;
+    ref_lt::Rectangle r(ref_lt::V3(c[0], c[1], c[2]), ref_lt::V3(c[3], c[4], c[5]), ref_lt::V3(c[6], c[7], c[8]),
+                        ref_lt::V3(c[9], c[10], c[11]));
+    if (normal3_out) put3(normal3_out, r.normal);
+    for (int i = 0; i < n; i++) {
+        const double* q = rays6 + 6 * i;
+        t_out[i] = r.intersect(ref_lt::Ray(ref_lt::V3(q[0], q[1], q[2]), ref_lt::V3(q[3], q[4], q[5])));
     }
     return 0;
 }

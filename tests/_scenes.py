@@ -134,3 +134,36 @@ def mt_rectangle_scene(seed, W, H, n_rect=7, n_sphere=5, n_plane=2, grid=True, w
                     b.corners[9 + c] += float(rng.normal() * warp)
     d.flags = pt.F_PIXEL_GRID if grid else 0
     return d
+
+
+def mt_edge_rays(d, rng, n_each=300):
+    """Rays aimed at corners, edges and the shared diagonal of every Moller-Trumbore rectangle."""
+    import numpy as np
+
+    rays = []
+    for i in range(d.body_count):
+        b = d.bodies[i]
+        if b.shape != pt.RECTANGLE_MT:
+            continue
+        p = np.array(list(b.corners)).reshape(4, 3)
+        for _ in range(n_each):
+            o = rng.uniform([-1.9, -2.5, -0.5], [1.9, 4.5, 2.5])
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                target = p[int(rng.integers(0, 4))]
+            elif kind == 1:
+                a = int(rng.integers(0, 4))
+                target = p[a] + rng.uniform() * (p[(a + 1) % 4] - p[a])
+            elif kind == 2:
+                target = p[0] + rng.uniform() * (p[2] - p[0])  # the diagonal both triangles share
+            else:
+                target = p[0] + rng.uniform() * (p[1] - p[0]) + rng.uniform() * (p[3] - p[0])
+            v = target - o
+            if kind != 3 and rng.uniform() < 0.5:
+                v /= np.linalg.norm(v)
+            rays.append(np.concatenate([o, v]))
+        # rays lying in the rectangle's plane (|det| tiny) and rays starting on it
+        e1, e2 = p[1] - p[0], p[2] - p[0]
+        rays.append(np.concatenate([p[0] - e1, e1 + 0.5 * e2]))
+        rays.append(np.concatenate([p[0] + 0.25 * e1 + 0.25 * e2, np.cross(e1, e2)]))
+    return np.array(rays)

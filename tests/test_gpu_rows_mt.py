@@ -15,35 +15,7 @@ from test_gpu_parity import oracle_scene
 pytestmark = pytest.mark.gpu
 
 
-def _edge_rays(d, rng, n_each=300):
-    """Rays aimed at corners, edges and the shared diagonal of every Moller-Trumbore rectangle."""
-    rays = []
-    for i in range(d.body_count):
-        b = d.bodies[i]
-        if b.shape != pt.RECTANGLE_MT:
-            continue
-        p = np.array(list(b.corners)).reshape(4, 3)
-        for _ in range(n_each):
-            o = rng.uniform([-1.9, -2.5, -0.5], [1.9, 4.5, 2.5])
-            kind = int(rng.integers(0, 4))
-            if kind == 0:
-                target = p[int(rng.integers(0, 4))]
-            elif kind == 1:
-                a = int(rng.integers(0, 4))
-                target = p[a] + rng.uniform() * (p[(a + 1) % 4] - p[a])
-            elif kind == 2:
-                target = p[0] + rng.uniform() * (p[2] - p[0])  # the diagonal both triangles share
-            else:
-                target = p[0] + rng.uniform() * (p[1] - p[0]) + rng.uniform() * (p[3] - p[0])
-            v = target - o
-            if kind != 3 and rng.uniform() < 0.5:
-                v /= np.linalg.norm(v)
-            rays.append(np.concatenate([o, v]))
-        # rays lying in the rectangle's plane (|det| tiny) and rays starting on it
-        e1, e2 = p[1] - p[0], p[2] - p[0]
-        rays.append(np.concatenate([p[0] - e1, e1 + 0.5 * e2]))
-        rays.append(np.concatenate([p[0] + 0.25 * e1 + 0.25 * e2, np.cross(e1, e2)]))
-    return np.array(rays)
+from _scenes import mt_edge_rays as _edge_rays  # noqa: E402
 
 
 @pytest.mark.parametrize("seed", range(40, 52))
@@ -141,3 +113,21 @@ def test_row_range_of_a_jittered_frame(port):
     assert same_bits(part[8:21], full[8:21])
     assert np.count_nonzero(part[:8]) == 0 and np.count_nonzero(part[21:]) == 0
     r.close()
+
+
+def test_moller_trumbore_rectangles_match_the_reference_class():
+    """pt_intersect_all on scenes made of the golden rectangles against what light_tracing.cpp's own
+    Rectangle::intersect returned for the same rays (tests/golden/light_rectangle.npz)."""
+    from test_light_tracing_glue import light_golden
+
+    meta, z = light_golden()
+    for m in meta:
+        corners, rays, want = z[m["key"] + "_corners"], z[m["key"] + "_rays"], z[m["key"] + "_t"]
+        n = corners.shape[0]
+        d = mt_rectangle_scene(m["seed"], 16, 16, n_rect=3 + m["seed"] % 5, n_sphere=0, n_plane=0, warp=m["warp"])
+        assert d.body_count == n
+        for i in range(n):
+            assert list(d.bodies[i].corners) == corners[i].tolist()  # the generator's scene, unchanged
+        r = pt.Renderer(d)
+        assert same_bits(r.intersect_all(rays).T, want), m["key"]
+        r.close()
