@@ -21,10 +21,18 @@ def test_compiled_sources_hold_no_boost():
     if not os.path.isdir(src):
         pytest.skip("the filtered sources stay in the build container")
     names = sorted(os.listdir(src))
-    assert len(names) == 8
+    assert len(names) == 9  # two parts of four programs, and the head of light_tracing.cpp
     for n in names:
         text = open(os.path.join(src, n)).read()
-        assert "boost" not in text and "threads" not in text, n
+        assert "boost" not in text and "threads" not in text and "kdtree" not in text, n
+    lt = os.path.join("/root/reference", "light_tracing.cpp")
+    if os.path.exists(lt):
+        # the head is the file's own lines up to `struct Scene`, minus the include lines and the mutex
+        whole = open(lt).read().splitlines()
+        cut = next(i for i, ln in enumerate(whole) if ln.startswith("struct Scene"))
+        want = [ln for ln in whole[:cut] if "boost" not in ln and "kdtree" not in ln]
+        assert open(os.path.join(src, "light_tracing.head.inc")).read().splitlines() == want
+        assert cut - len(want) == 6
     # what was left out is the thread glue and nothing else: 10-12 lines per program
     for prog in ("main", "next_event", "raytrace3", "bidirectional"):
         ref = os.path.join("/root/reference", prog + ".cpp")
