@@ -17,3 +17,4 @@ timeout -k 10 300 python3 bench.py --no-cpu --scene synthetic10k --iterations 63
 ls $out $out/trace
 timeout -k 10 200 python3 bench.py --no-cpu --pipeline wavefront --iterations 240 > $out/bench_nee15_wavefront.json 2>> $out/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu --scene light_room32 --iterations 720 > $out/bench_light_room32.json 2>> $out/bench.err || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu --scene bidir32 --iterations 720 > $out/bench_bidir32.json 2>> $out/bench.err || exit 1
