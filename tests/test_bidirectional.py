@@ -207,3 +207,25 @@ def test_gpu_drop_in_executable(port, tmp_path):
         total = total + priv
     with open(out, "rb") as f:
         assert f.read() == port.save_ppm(total, iters, W, H)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [4, 5, 9, 10, 44, 46, 54])
+def test_gpu_scenes_without_planes_under_every_estimator(port, seed):
+    """Scenes made of spheres only: most camera rays miss, so the second phase of an estimator (shadow
+    rays, light path) is run by lanes that left the gather loop at once, while the scan's plane list
+    and slabs are empty.  Both shadow-origin modes of next-event estimation, path tracing, and the
+    bidirectional estimator against the oracle."""
+    from test_gpu_parity import random_scene
+
+    W, H = 40, 24
+    base = random_scene(seed, W, H)
+    assert all(base.bodies[i].shape == pt.SPHERE for i in range(base.body_count))
+    for est, flags in ((pt.EST_NEE, 0), (pt.EST_NEE, pt.F_LIGHT_TRUE_CENTER), (pt.EST_PT, 0), (pt.EST_BIDIR, 0)):
+        d = random_dark_scene(seed, W, H) if est == pt.EST_BIDIR else random_scene(seed, W, H)
+        d.estimator = est
+        d.flags = flags
+        r = pt.Renderer(d)
+        want, _ = port.render(oracle_scene(port, r, W, H, seed, flags=flags), MODE_PIXEL, 0, 3)
+        assert same_bits(r.render(0, 3), want), (seed, est, flags)
+        r.close()
