@@ -133,9 +133,12 @@ int pt_scene_bodies(const pt_scene* scene, pt_body* out, int cap);
 int pt_brdf_upload(pt_scene* scene, int brdf_id, const double* table, size_t n_doubles);
 int pt_brdf_load_file(pt_scene* scene, int brdf_id, const char* path);
 
-/* Multi-GPU sharding: this handle renders only the destination tiles (tile_w x tile_h pixels,
- * numbered row-major) whose index % world == rank; other pixels of `accum` are left untouched.
- * Default: rank 0 of 1.  The reference's counterpart is worker()'s per-thread split
+/* Multi-GPU sharding: this handle renders only the destination tiles (tile_w x tile_h pixels)
+ * whose number % world == rank; other pixels of `accum` are left untouched.  Tiles are numbered
+ * along the tile rows, every row starting one column further right than the one above: number
+ * ty * tiles_x + c is the tile at column (c + ty) % tiles_x of tile row ty (tiles_x = ceil(width /
+ * tile_w)), so that a rank's tiles do not line up in columns of the picture when tiles_x is a
+ * multiple of world.  Default: rank 0 of 1.  The reference's counterpart is worker()'s per-thread split
  * (main.cpp:436-458, 642-645). */
 int pt_set_partition(pt_scene* scene, int rank, int world, int tile_w, int tile_h);
 

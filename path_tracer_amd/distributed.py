@@ -2,8 +2,10 @@
 
 The reference splits a render over N threads, each adding full frames into a private buffer that is
 summed under a mutex at the end (main.cpp:436-458, 642-654).  Here rank r of N renders only the
-32x8-pixel destination tiles whose row-major index is congruent to r modulo N (pt_set_partition)
-and leaves every other pixel of its FP64 accumulator untouched.  Tiles are disjoint, so the one
+32x8-pixel destination tiles whose number is congruent to r modulo N (pt_set_partition) and leaves
+every other pixel of its FP64 accumulator untouched.  Tile numbers run along the tile rows, each
+row starting one column further right than the row above (number ty*tiles_x + c sits at column
+(c + ty) % tiles_x), so that a rank's tiles do not line up in columns of the picture.  Tiles are disjoint, so the one
 exchange step is an all-gather of the owned tiles (each rank sends W*H*3/N doubles; `Exchange`);
 the older form, an all-reduce (sum) of the zero-padded W*H*3 accumulators, is kept
 (`all_reduce_accumulator`) and gives the same bits, since x + 0.0 == x.  Either way the frame is
@@ -20,7 +22,7 @@ def tile_owner(width, height, world, tile_w=TILE_W, tile_h=TILE_H):
     tiles_x = (width + tile_w - 1) // tile_w
     ty = np.arange(height)[:, None] // tile_h
     tx = np.arange(width)[None, :] // tile_w
-    return ((ty * tiles_x + tx) % world).astype(np.int32)
+    return ((ty * tiles_x + (tx - ty) % tiles_x) % world).astype(np.int32)
 
 
 def owned_mask(width, height, rank, world, tile_w=TILE_W, tile_h=TILE_H):
@@ -35,7 +37,8 @@ def tiles_per_rank(width, height, world, tile_w=TILE_W, tile_h=TILE_H):
 def _tile_slots(width, height, tile, tile_w, tile_h):
     """Destination pixel index of each of the 256 pixels of tile `tile` (-1 outside the image)."""
     tiles_x = -(-width // tile_w)
-    tx, ty = tile % tiles_x, tile // tiles_x
+    ty = tile // tiles_x
+    tx = (tile % tiles_x + ty) % tiles_x
     px = tx * tile_w + np.arange(tile_w * tile_h) % tile_w
     py = ty * tile_h + np.arange(tile_w * tile_h) // tile_w
     return np.where((px < width) & (py < height), py * width + px, -1)
