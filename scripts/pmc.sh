@@ -12,7 +12,7 @@ run() { # name counters...
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --no-cpu "${BENCH_ARGS[@]}" > $out/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/$name.log; return 1; }
 }
 BENCH_ARGS=("$@")
-[ ${#BENCH_ARGS[@]} -eq 0 ] && BENCH_ARGS=(--iterations 42 --steps 1 --warmup 0)
+[ ${#BENCH_ARGS[@]} -eq 0 ] && BENCH_ARGS=(--iterations 40 --steps 1 --warmup 0)
 run p1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY &&
 run p2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU &&
 run p3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_IFETCH &&

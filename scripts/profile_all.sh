@@ -7,6 +7,6 @@ half=$2
 if [ "$half" = a ]; then
   scripts/profile_round.sh $tag && scripts/bench_configs.sh $tag
 else
-  scripts/pmc.sh $tag && scripts/pmc.sh ${tag}_meas --scene nee15_measured --iterations 42 --steps 1 --warmup 0 &&
+  scripts/pmc.sh $tag && scripts/pmc.sh ${tag}_meas --scene nee15_measured --iterations 40 --steps 1 --warmup 0 &&
   scripts/c5_prof.sh $tag && scripts/c5_traffic.sh $tag > gpurun_out/c5tr_$tag.txt && cat gpurun_out/c5tr_$tag.txt
 fi
