@@ -57,6 +57,14 @@ void pt_normalize3(double x, double y, double z, double* o) {
 }
 
 constexpr int kBlock = 256;
+// Threads of an estimator block: a whole tile, or one wave of it for the path tracer, whose blocks
+// hold no LDS records: a wave that has finished then frees its slot without waiting for the other
+// three of its tile (main32 9.73e9 -> 9.94e9 paths/s).  The next-event kernels measured 1-6 % slower
+// with 128- or 64-thread blocks and keep the tile.
+#ifndef PT_TRACE_BLOCK_PT
+#define PT_TRACE_BLOCK_PT 64
+#endif
+constexpr int trace_block(int est) { return est == 0 /* kEstPT */ ? PT_TRACE_BLOCK_PT : kBlock; }
 constexpr int kXcdsLog2 = 3;  // eight accelerator dies; the blocks of a grid go to them in turn
 constexpr int kXStride = 8;  // the x running sum of a row is stored at every 8th column
 
@@ -195,25 +203,28 @@ void launch_frame_layout(hipStream_t st, uint64_t seed, int W, int H, int first_
 // keeps four positions per path in LDS (26 368 B per block) and fits 80 VGPRs: six blocks per CU.
 // The path-tracing kernel keeps no positions and fits 64 VGPRs: eight.
 template <int EST, bool MEASURED, bool COMPACT = false>
-__global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, int n_it, const double* __restrict__ xs,
+__global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, int n_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ npix, double xstep,
                                                   double* __restrict__ samples, size_t sample_stride) {
     // path tracing keeps no vertex positions; the compact next-event form keeps the deepest vertex's in
     // registers (see trace_path_nee_compact), which lets a sixth block share the CU's LDS
-    __shared__ double s_pts[EST == kEstPT ? 1 : (COMPACT ? kMaxDepth - 1 : kMaxDepth) * 3 * kBlock];
-    __shared__ int8_t s_bod[kMaxDepth * kBlock];
-    __shared__ uint16_t s_slots[COMPACT ? kBlock : 1];
+    constexpr int kTraceBlock = trace_block(EST), kTraceParts = kBlock / kTraceBlock;
+    __shared__ double s_pts[EST == kEstPT ? 1 : (COMPACT ? kMaxDepth - 1 : kMaxDepth) * 3 * kTraceBlock];
+    __shared__ int8_t s_bod[kMaxDepth * kTraceBlock];
+    __shared__ uint16_t s_slots[COMPACT ? kTraceBlock : 1];
     const int tid = threadIdx.x;
     // blockIdx.x = (owned tile << gl) + g, iteration b = (blockIdx.y << gl) + g: see launch_trace
     const int gl = P.group_log2;
     const int b = (blockIdx.y << gl) + (blockIdx.x & ((1 << gl) - 1));
     if (b >= n_it) return;
-    const int q = blockIdx.x >> gl;
+    const int qp = blockIdx.x >> gl;
+    const int q = qp / kTraceParts;
+    const int ttid = (qp % kTraceParts) * kTraceBlock + tid;  // thread's place in the tile
     const int W = S.width, H = S.height;
     int dest_row;
-    const int slot = slot_of(P, q, tid, W, H, &dest_row);
-    const size_t j = (size_t)q * kBlock + tid;
+    const int slot = slot_of(P, q, ttid, W, H, &dest_row);
+    const size_t j = (size_t)q * kBlock + ttid;
     double* out = samples + (size_t)b * 3 * sample_stride + j;
     V3 rgb = mk(0.0, 0.0, 0.0);
 #ifdef PT_PROFILE_SECTIONS
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(kBlock, EST == kEstPT ? 8 : COMPACT ? 6 : 5) k
     Records rec;
     rec.pts = s_pts;
     rec.bod = s_bod;
-    rec.stride = kBlock;
+    rec.stride = kTraceBlock;
     rec.tid = tid;
     if (COMPACT) {
         rgb = trace_path_nee_compact(S, dr, valid, x, y, rec, s_slots + (tid & ~63));
@@ -1415,9 +1426,10 @@ void launch_trace(const pt_scene* s, hipStream_t st, const Partition& P0, int it
     P.group_log2 = kXcdsLog2;
     while (P.group_log2 > 0 && (1 << P.group_log2) > B) P.group_log2--;
     const int G = 1 << P.group_log2;
-    const dim3 grid((unsigned)P.owned_tiles * G, (unsigned)((B + G - 1) / G));
-#define PT_LAUNCH_TRACE(...) \
-    hipLaunchKernelGGL((k_trace<__VA_ARGS__>), grid, dim3(kBlock), 0, st, s->ds, P, it0, B, xs, ys, rs, npix, s->xstep, samples, J)
+    const dim3 grid_tile((unsigned)P.owned_tiles * G, (unsigned)((B + G - 1) / G));
+    const dim3 grid_pt(grid_tile.x * (kBlock / trace_block(kEstPT)), grid_tile.y);
+#define PT_LAUNCH_TRACE(EST_, ...) \
+    hipLaunchKernelGGL((k_trace<EST_, __VA_ARGS__>), EST_ == kEstPT ? grid_pt : grid_tile, dim3(trace_block(EST_)), 0, st, s->ds, P, it0, B, xs, ys, rs, npix, s->xstep, samples, J)
     if (s->estimator == PT_EST_BIDIR)
         PT_LAUNCH_TRACE(kEstBidir, false);
     else if (s->estimator == PT_EST_NEE && s->ds.nee_emission_only)
