@@ -3,7 +3,7 @@
 // kernel over a compacted queue of live paths, and the nearest-hit scan walks a bounding hierarchy
 // of the spheres with scalar loads.
 //
-//   k_wf_generate        camera rays, per-path RNG streams, queue 0
+//   k_wf_primary         camera rays, per-path RNG streams, their nearest hit, queue 0
 //   k_wf_extend<GATHER>  nearest hit of the current ray           (main.cpp:372-383)
 //   k_wf_shade           point / normal / bounce / offset / record (main.cpp:391-403), queue d+1 and its sort keys
 //   k_wf_light           light pick                                (next_event.cpp:390), shadow queues and their sort keys
@@ -389,48 +389,60 @@ PTD_INLINE int nearest_hit_grouped(const DScene& S, V3 o, V3 d, int skip, double
 
 // ---- kernels ---------------------------------------------------------------------------------
 
-// grid (owned tiles, iterations of the batch); path id = b * J + j with j = tile * 256 + tid.
+// The first stage: camera ray, per-path RNG stream and the nearest hit of the camera ray in one kernel
+// (the rays leave it in pixel order, which is as coherent as a sort would make them, and a separate
+// generating stage would write 64-byte ray records only for the first scan to read them back).
+// One wave to a block, as in k_wf_extend; grid (4 * owned tiles, iterations of the batch); path id
+// p = b * J + j with j = tile * 256 + place in the tile.  Queue 0 is every path id of the batch in
+// order, the few without a sample (outside the image or the row range, past a short frame's end)
+// included: they carry hit = -1, no records and no shadow tasks, so every later stage passes them by
+// and their sample slot, which the accumulation never reads, is written as zero.
 template <class PartitionT, class SlotFn>
-__device__ inline void wf_generate_body(const DScene& S, const PartitionT& P, SlotFn slot_of_fn, int first_it,
-                                        const double* __restrict__ xs, const double* __restrict__ ys,
-                                        const int32_t* __restrict__ row_start, const int32_t* __restrict__ npix,
-                                        double xstep, int xstride, WfState W, size_t J) {
-    const int tid = threadIdx.x;
+__device__ inline void wf_primary_body(const DScene& S, const PartitionT& P, SlotFn slot_of_fn, int first_it,
+                                       const double* __restrict__ xs, const double* __restrict__ ys,
+                                       const int32_t* __restrict__ row_start, const int32_t* __restrict__ npix,
+                                       double xstep, int xstride, WfState W, size_t J, int n_it, uint4* tile) {
+    const int lane = threadIdx.x;  // blocks of one wave
     const int b = blockIdx.y;
+    const int q = blockIdx.x >> 2, ttid = (int)(blockIdx.x & 3u) * 64 + lane;
     const int Wd = S.width, H = S.height;
-    const int slot = slot_of_fn(P, blockIdx.x, tid, Wd, H);
-    const size_t p = (size_t)b * J + (size_t)blockIdx.x * kWfBlock + tid;
+    const int slot = slot_of_fn(P, q, ttid, Wd, H);
+    const size_t p = (size_t)b * J + (size_t)q * kWfBlock + ttid;
     const bool valid = slot >= 0 && slot < npix[b];
     RayRec rr;
     rr.ox = rr.oy = rr.oz = rr.dx = rr.dy = rr.dz = rr.t = 0.0;
     rr.hit = -1, rr.pad = 0;
+    Rng rng = {0u, 0u, 0u, 0u};
+    double x = 0.0, y = 0.0;
     if (valid) {
         const int32_t* rs = row_start + (size_t)b * (H + 1);
         int r = slot / Wd;
         while (slot >= rs[r + 1]) r++;
         int c = slot - rs[r];
         const int CK = (Wd + xstride - 1) / xstride;
-        double x;
         if (S.flags & 4u) {
             x = (double)c / (double)Wd;  // light_tracing.cpp:787
         } else {
             x = xs[((size_t)b * CK + c / xstride) * H + r];
             for (int i = c % xstride; i > 0; --i) x += xstep;
         }
-        double y = ys[(size_t)b * H + r];
+        y = ys[(size_t)b * H + r];
         V3 o = ld3(S.cam_o);
         V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157
         rr.ox = o.x, rr.oy = o.y, rr.oz = o.z, rr.dx = d.x, rr.dy = d.y, rr.dz = d.z;
-        W.xy[p] = x;
-        W.xy[W.cap + p] = y;
-        store_rng(W, p, rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot));
-        W.nrec[p] = 0;
-        W.need[p] = 0;
+        rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
+        double mint;
+        rr.hit = nearest_hit_grouped(S, o, d, -1, mint);
+        rr.t = mint;
     }
-    __shared__ uint4 s_tile[kWfBlock * 4];
-    wave_store_rays(W.rays, (uint32_t)p, valid, rr, s_tile + (threadIdx.x >> 6) * 256);
-    __shared__ int32_t s_push[kWfBlock / 64 + 1];
-    queue_push(W.queue, W.qcount, valid, (int)p, s_push);
+    PT_NT1(x, W.xy + p);
+    PT_NT1(y, W.xy + W.cap + p);
+    store_rng(W, p, rng);
+    PT_NT1(0, W.nrec + p);
+    PT_NT1(0, W.need + p);
+    PT_NT1((int32_t)p, W.queue + p);
+    wave_store_rays<4>(W.rays, (uint32_t)p, true, rr, tile);
+    if (blockIdx.x == 0 && b == 0 && lane == 0) W.qcount[0] = (int32_t)(J * (size_t)n_it);
 }
 
 enum { kGather = 0, kShadow = 1 };

@@ -290,14 +290,15 @@ __global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT 
     out[2 * sample_stride] = rgb.z;
 }
 
-// ---- wavefront pipeline: generate stage (the other stages are in pt_wavefront.hpp) -----------
-__global__ void __launch_bounds__(kBlock) k_wf_generate(DScene S, Partition P, int first_it,
-                                                        const double* __restrict__ xs, const double* __restrict__ ys,
-                                                        const int32_t* __restrict__ row_start,
-                                                        const int32_t* __restrict__ npix, double xstep, ptw::WfState W,
-                                                        size_t J) {
-    ptw::wf_generate_body(S, P, [](const Partition& Pp, int q, int tid, int Wd, int H) { return slot_of(Pp, q, tid, Wd, H); },
-                          first_it, xs, ys, row_start, npix, xstep, kXStride, W, J);
+// ---- wavefront pipeline: first stage (the other stages are in pt_wavefront.hpp) ---------------
+__global__ void __launch_bounds__(ptw::kExtBlock) k_wf_primary(DScene S, Partition P, int first_it, int n_it,
+                                                                const double* __restrict__ xs, const double* __restrict__ ys,
+                                                                const int32_t* __restrict__ row_start,
+                                                                const int32_t* __restrict__ npix, double xstep, ptw::WfState W,
+                                                                size_t J) {
+    __shared__ uint4 s_tile[64 * 4];
+    ptw::wf_primary_body(S, P, [](const Partition& Pp, int q, int tid, int Wd, int H) { return slot_of(Pp, q, tid, Wd, H); },
+                         first_it, xs, ys, row_start, npix, xstep, kXStride, W, J, n_it, s_tile);
 }
 
 // ---- k_accumulate ------------------------------------------------------------------------
@@ -1320,9 +1321,9 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const int nblk_push = (int)((J * (size_t)B + kPushBlock - 1) / kPushBlock);
     const int nblk_ext = (int)((J * (size_t)B + kExtBlock - 1) / kExtBlock);
     HIP_TRY(hipMemsetAsync(W.qcount, 0, 16 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_wf_generate, dim3(P.owned_tiles, B), dim3(kBlock), 0, st, s->ds, P, it0, xs, ys, rs, npix, s->xstep, W, J);
+    hipLaunchKernelGGL(k_wf_primary, dim3(P.owned_tiles * 4, B), dim3(kExtBlock), 0, st, s->ds, P, it0, B, xs, ys, rs, npix, s->xstep, W, J);
     // the rays of a queue are put in key order before the scan (not the primary rays, which
-    // leave k_wf_generate in pixel order)
+    // k_wf_primary scans in pixel order)
     // (the keys of a gather queue were written by the shading stage that filled it)
     const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
     // The library sort takes its size from the host.  Only the first n entries of a queue are sorted,
@@ -1361,10 +1362,11 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         return W.sorted;
     };
     for (int depth = 0; depth < kMaxDepth; ++depth) {
-        int n_sorted = 0;
-        const int32_t* list = W.sorted;
-        if (depth > 0) list = sorted_list(kGather, depth, 0, &n_sorted);  // the primary rays stay in pixel order
-        hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list, n_sorted);
+        if (depth > 0) {  // k_wf_primary has scanned the camera rays
+            int n_sorted = 0;
+            const int32_t* list = sorted_list(kGather, depth, 0, &n_sorted);
+            hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list, n_sorted);
+        }
         if (s->wf_sort && depth + 1 < kMaxDepth) {  // the next queue will be sorted: end keys everywhere, then the survivors' keys
             HIP_TRY(hipMemsetAsync(W.keys, 0xFF, (size_t)cap * sizeof(uint32_t), st));
             hipLaunchKernelGGL(k_wf_shade<true>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
