@@ -1,22 +1,25 @@
 // Wavefront form of the estimator for scenes too large for the fused kernel: path state lives in
-// HBM (a ray record and vertex records per path, columns for the rest), each stage is its own
-// kernel over a compacted queue of live paths, and the nearest-hit scan walks a bounding hierarchy
-// of the spheres with scalar loads.
+// HBM (a 64-byte record with the ray and the random stream, and vertex records, per path; columns for
+// the rest), each stage is its own kernel, and the nearest-hit scan walks a bounding hierarchy of the
+// spheres with scalar loads.
 //
-//   k_wf_primary         camera rays, per-path RNG streams, their nearest hit, queue 0
-//   k_wf_extend<GATHER>  nearest hit of the current ray           (main.cpp:372-383)
-//   k_wf_shade           point / normal / bounce / offset / record (main.cpp:391-403), queue d+1 and its sort keys
+//   k_wf_primary         camera rays and per-path RNG streams, then as k_wf_bounce at depth 0
+//   k_wf_bounce          nearest hit of the path's ray (main.cpp:372-383) and, in the same kernel, point /
+//                        normal / bounce / offset / record (main.cpp:391-403), the path's entry for the
+//                        next depth and its sort key
 //   k_wf_light           light pick                                (next_event.cpp:390), shadow queues and their sort keys
-//   k_wf_extend<SHADOW>  nearest hit of the shadow ray, light excluded (next_event.cpp:405-426)
+//   k_wf_shadow          nearest hit of the shadow ray, light excluded (next_event.cpp:405-426)
 //   k_wf_nee_finish      visibility tests + colour recurrence     (next_event.cpp:428-463), the sample
 //   k_wf_finish          plain path tracing: Horner, the sample
-// Between a queue's filling and its scan the host queues one radix sort of (key, path id) pairs.
+// Between two depths the host queues one radix sort of (key, path id) pairs, and one per shadow queue.
 //
-// A path that leaves the scene is not pushed to the next queue, so later stages run on dense
-// waves only (wave64 ballot, one atomic per block).  Queue d+1 holds the paths with more than d
-// recorded vertices; k_wf_light fills one shadow-task queue per vertex, one scan each; the colour
-// recurrence then walks a path's vertices deepest first.  The arithmetic of every
-// stage is the same device code the fused kernel uses, so both pipelines give identical bits.
+// The gather entries of depth d+1 are written at the positions the threads of depth d hold: the
+// path id of a survivor with its key, or -1 with the end key for a path that left the scene (or a
+// slot without a sample), so the list needs no counter and no atomic; the sort moves the dead entries
+// behind the live ones, where whole waves of them return at once.  k_wf_light fills one compacted
+// shadow-task queue per vertex, one scan each; the colour recurrence then walks a path's vertices
+// deepest first.  The arithmetic of every stage is the same device code the fused kernel uses, so
+// both pipelines give identical bits.
 #pragma once
 #include "pt_device.hpp"
 
@@ -29,11 +32,9 @@ constexpr int kWfBlock = 256;
 // The scans visit the paths in ray-key order, i.e. at scattered path ids: what a scan reads and
 // writes per path is kept together so that it costs one cache line, not one per component (as
 // structure-of-arrays columns the gather scans fetched 600 B per ray from HBM).
-struct alignas(64) RayRec {  // the path's current ray and the result of its scan
+struct alignas(64) RayRec {  // the path's current ray and its random stream
     double ox, oy, oz, dx, dy, dz;
-    double t;     // distance of the last scan
-    int32_t hit;  // body of the last scan
-    int32_t pad;
+    uint32_t s0, s1, s2, s3;
 };
 struct alignas(32) VertexRec {  // a recorded vertex: the offset point and its body
     double x, y, z;
@@ -111,14 +112,14 @@ struct WfState {
     RayRec* rays;      // [cap]
     VertexRec* verts;  // [kMaxDepth][cap]
     double* xy;      // [2][cap]  image-plane coordinates of the sample
-    uint32_t* rng;   // [4][cap]
+    uint4* rng;      // [cap]     the stream after the light pick (k_wf_light -> k_wf_nee_finish)
     int32_t* nrec;   // [cap]
     int32_t* light;  // [cap]
     int32_t* need;   // [cap]     1 + deepest emitting vertex (scenes with a dead direct term), else 0
-    int32_t* queue;  // [11][cap] 0..5: paths with more than d-1 records; 6..10: shadow tasks of vertex 0..4
+    int32_t* queue;  // [11][cap] 0: every path id; 1..4: the gather entries of that depth (path id or -1 by position); 6..10: shadow tasks of vertex 0..4
     int32_t* qcount; // [16]
     int32_t* sorted; // [cap]     a queue reordered by ray key (see ray_key)
-    uint32_t* keys;  // [cap]     sort keys of the next gather queue, by queue position
+    uint32_t* keys;  // [cap]     sort keys of the next depth's gather entries, by position
     uint32_t* skeys; // [5][cap]  sort keys of the shadow-task queues
     size_t cap;
 };
@@ -151,19 +152,10 @@ PTD_INLINE int queue_push(int32_t* q, int32_t* count, bool pred, int value, int3
     return pred ? pos : -1;
 }
 
-PTD_INLINE Rng load_rng(const WfState& W, size_t p) {
+PTD_INLINE Rng rng_of(const uint4& v) {
     Rng r;
-    r.s0 = W.rng[p];
-    r.s1 = W.rng[W.cap + p];
-    r.s2 = W.rng[2 * W.cap + p];
-    r.s3 = W.rng[3 * W.cap + p];
+    r.s0 = v.x, r.s1 = v.y, r.s2 = v.z, r.s3 = v.w;
     return r;
-}
-PTD_INLINE void store_rng(const WfState& W, size_t p, const Rng& r) {
-    PT_NT1(r.s0, W.rng + p);
-    PT_NT1(r.s1, W.rng + W.cap + p);
-    PT_NT1(r.s2, W.rng + 2 * W.cap + p);
-    PT_NT1(r.s3, W.rng + 3 * W.cap + p);
 }
 PTD_INLINE V3 load3(const double* a, size_t cap, size_t p, int first) {
     return mk(a[(size_t)first * cap + p], a[(size_t)(first + 1) * cap + p], a[(size_t)(first + 2) * cap + p]);
@@ -389,83 +381,7 @@ PTD_INLINE int nearest_hit_grouped(const DScene& S, V3 o, V3 d, int skip, double
 
 // ---- kernels ---------------------------------------------------------------------------------
 
-// The first stage: camera ray, per-path RNG stream and the nearest hit of the camera ray in one kernel
-// (the rays leave it in pixel order, which is as coherent as a sort would make them, and a separate
-// generating stage would write 64-byte ray records only for the first scan to read them back).
-// One wave to a block, as in k_wf_extend; grid (4 * owned tiles, iterations of the batch); path id
-// p = b * J + j with j = tile * 256 + place in the tile.  Queue 0 is every path id of the batch in
-// order, the few without a sample (outside the image or the row range, past a short frame's end)
-// included: they carry hit = -1, no records and no shadow tasks, so every later stage passes them by
-// and their sample slot, which the accumulation never reads, is written as zero.
-template <class PartitionT, class SlotFn>
-__device__ inline void wf_primary_body(const DScene& S, const PartitionT& P, SlotFn slot_of_fn, int first_it,
-                                       const double* __restrict__ xs, const double* __restrict__ ys,
-                                       const int32_t* __restrict__ row_start, const int32_t* __restrict__ npix,
-                                       double xstep, int xstride, WfState W, size_t J, int n_it, uint4* tile) {
-    const int lane = threadIdx.x;  // blocks of one wave
-    const int b = blockIdx.y;
-    const int q = blockIdx.x >> 2, ttid = (int)(blockIdx.x & 3u) * 64 + lane;
-    const int Wd = S.width, H = S.height;
-    const int slot = slot_of_fn(P, q, ttid, Wd, H);
-    const size_t p = (size_t)b * J + (size_t)q * kWfBlock + ttid;
-    const bool valid = slot >= 0 && slot < npix[b];
-    RayRec rr;
-    rr.ox = rr.oy = rr.oz = rr.dx = rr.dy = rr.dz = rr.t = 0.0;
-    rr.hit = -1, rr.pad = 0;
-    Rng rng = {0u, 0u, 0u, 0u};
-    double x = 0.0, y = 0.0;
-    if (valid) {
-        const int32_t* rs = row_start + (size_t)b * (H + 1);
-        int r = slot / Wd;
-        while (slot >= rs[r + 1]) r++;
-        int c = slot - rs[r];
-        const int CK = (Wd + xstride - 1) / xstride;
-        if (S.flags & 4u) {
-            x = (double)c / (double)Wd;  // light_tracing.cpp:787
-        } else {
-            x = xs[((size_t)b * CK + c / xstride) * H + r];
-            for (int i = c % xstride; i > 0; --i) x += xstep;
-        }
-        y = ys[(size_t)b * H + r];
-        V3 o = ld3(S.cam_o);
-        V3 d = normalize(sub(cam_point(S, x, y), o));  // Camera::getRay main.cpp:154-157
-        rr.ox = o.x, rr.oy = o.y, rr.oz = o.z, rr.dx = d.x, rr.dy = d.y, rr.dz = d.z;
-        rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
-        double mint;
-        rr.hit = nearest_hit_grouped(S, o, d, -1, mint);
-        rr.t = mint;
-    }
-    PT_NT1(x, W.xy + p);
-    PT_NT1(y, W.xy + W.cap + p);
-    store_rng(W, p, rng);
-    PT_NT1(0, W.nrec + p);
-    PT_NT1(0, W.need + p);
-    PT_NT1((int32_t)p, W.queue + p);
-    wave_store_rays<4>(W.rays, (uint32_t)p, true, rr, tile);
-    if (blockIdx.x == 0 && b == 0 && lane == 0) W.qcount[0] = (int32_t)(J * (size_t)n_it);
-}
-
 enum { kGather = 0, kShadow = 1 };
-
-
-// The ray of entry i of queue qi: the path's current ray, or the shadow ray towards vertex gi.
-template <int MODE>
-PTD_INLINE void queue_ray(const DScene& S, const WfState& W, size_t p, int gi, V3& o, V3& d, int& skip) {
-    if (MODE == kGather) {
-        const RayRec* rr = W.rays + p;
-        o = mk(rr->ox, rr->oy, rr->oz);
-        d = mk(rr->dx, rr->dy, rr->dz);
-        skip = -1;
-    } else {
-        const VertexRec v = W.verts[(size_t)gi * W.cap + p];
-        const int light = v.shadow;
-        const V3 lc = light_origin(S, light);
-        V3 Pt = mk(v.x, v.y, v.z);
-        o = lc;
-        d = normalize(sub(Pt, lc));  // next_event.cpp:405-407
-        skip = light;
-    }
-}
 
 // Rays are reordered before a scan so that the 64 rays of a wave start near one another and
 // point the same way: a wave then enters few of the body groups.  The key is a cell of the
@@ -527,75 +443,141 @@ constexpr uint32_t kShadowKeyBits = 16;         // shadow rays: 6 * 64 * 64 cell
 static_assert(6ull * PT_KEY_D * PT_KEY_D * PT_KEY_O * PT_KEY_O * PT_KEY_O < (1ull << PT_KEY_BITS) - 1, "gather keys must stay below the end key");
 static_assert(6ull * 64 * 64 < (1ull << kShadowKeyBits) - 1, "shadow keys must stay below the end key");
 
-// One ray per thread over the paths of queue `qi`; gi is the vertex whose shadow ray is cast.  The
-// first n_sorted entries are taken in the order of `sorted`, the rest in the queue's own.
-// One wave to a block: nothing is shared between waves, and a block of one ends as soon as its
-// own rays are done.
 constexpr int kExtBlock = 64;
-template <int MODE>
-__global__ void __launch_bounds__(kExtBlock) k_wf_extend(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ sorted, int n_sorted) {
+constexpr uint32_t kEndKey = 0xffffffffu;  // sorts behind every ray key
+
+// After the scan of a gather ray: shade the hit (main.cpp:391-403), record the vertex, store the
+// path's new ray and stream, and write position i of the next depth's entries.  `live`: the lane holds
+// a path (rec is its record, hit / t the result of its scan); every lane of the wave must call.
+// A path's record count goes to W.nrec once, where the path ends.
+template <bool KEYS, bool FIRST>
+PTD_INLINE void wf_shade_and_store(const DScene& S, const WfState& W, int depth, size_t i, uint32_t p, bool live, RayRec rec,
+                                   int hit, double t, V3 eye_point, uint4* tile) {
+    bool alive = false;
+    VertexRec v;
+    v.x = v.y = v.z = 0.0, v.body = -1, v.shadow = -1;
+    uint32_t key = kEndKey;
+    if (live) {
+        if (hit >= 0) {
+            alive = true;
+            V3 o = mk(rec.ox, rec.oy, rec.oz), d = mk(rec.dx, rec.dy, rec.dz);
+            Draws dr;
+            dr.rng.s0 = rec.s0, dr.rng.s1 = rec.s1, dr.rng.s2 = rec.s2, dr.rng.s3 = rec.s3;
+            dr.count = 0;
+            const DMat& m = S.mat[hit];
+            // the vertex before this one: the ray origin, or the camera-plane point for the first
+            const V3 prev = depth > 0 ? o : eye_point;
+            V3 point = shade_hit(S.geom[hit], m, dr, o, d, t);
+            if (m.emits | ((m.material != kDiffuse) & same_point(point, prev))) W.need[p] = depth + 1;  // see trace_path_nee_compact
+            v.x = point.x, v.y = point.y, v.z = point.z, v.body = hit;
+            rec.ox = o.x, rec.oy = o.y, rec.oz = o.z, rec.dx = d.x, rec.dy = d.y, rec.dz = d.z;
+            rec.s0 = dr.rng.s0, rec.s1 = dr.rng.s1, rec.s2 = dr.rng.s2, rec.s3 = dr.rng.s3;
+            if (KEYS) key = ray_key<kGather>(S, o, d);
+        }
+        if (!alive || depth == kMaxDepth - 1) PT_NT1(alive ? depth + 1 : depth, W.nrec + p);
+    }
+    // (the first stage stores the record of a camera ray that hits nothing too: the light pick reads its stream)
+    wave_store_rays<4>(W.rays, p, FIRST ? live : alive, rec, tile);
+    wave_store_verts(W.verts + (size_t)depth * W.cap, p, alive, v, tile);
+    if (depth + 1 < kMaxDepth && i < W.cap) {
+        PT_NT1(alive ? (int32_t)p : -1, W.queue + (size_t)(depth + 1) * W.cap + i);
+        if (KEYS) PT_NT1(key, W.keys + i);
+    }
+}
+
+// Depth >= 1: one path per thread over the n_entries positions of the depth's entries, the first
+// n_sorted of them in the order of `sorted`, the rest in their own.  One wave to a block: nothing is
+// shared between waves, and a block of one ends as soon as its own rays are done.
+template <bool KEYS>
+__global__ void __launch_bounds__(kExtBlock) k_wf_bounce(DScene S, WfState W, int depth, const int32_t* __restrict__ sorted, int n_sorted,
+                                                         int n_entries) {
+    const size_t i = (size_t)blockIdx.x * kExtBlock + threadIdx.x;
+    if ((size_t)blockIdx.x * kExtBlock >= (size_t)n_entries) return;  // whole waves only: the record moves below are wave-wide
+    const bool inside = i < (size_t)n_entries;                        // (n_entries is a multiple of 256 in every caller)
+    int32_t id = -1;
+    if (inside) id = i < (size_t)n_sorted ? sorted[i] : W.queue[(size_t)depth * W.cap + i];
+    const bool live = id >= 0;
+    const uint32_t p = live ? (uint32_t)id : 0u;
+    __shared__ uint4 s_tile[64 * 4];
+    RayRec rec = wave_load_rays(W.rays, p, live, s_tile);
+    int hit = -1;
+    double t = 0.0;
+    if (live) hit = nearest_hit_grouped(S, mk(rec.ox, rec.oy, rec.oz), mk(rec.dx, rec.dy, rec.dz), -1, t);
+    wf_shade_and_store<KEYS, false>(S, W, depth, i, p, live, rec, hit, t, mk(0.0, 0.0, 0.0), s_tile);
+}
+
+// The shadow ray towards vertex gi of every task of queue qi (next_event.cpp:405-407): from the light's
+// origin, the light excluded from the scan; the vertex record receives the body it hit.
+__global__ void __launch_bounds__(kExtBlock) k_wf_shadow(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ sorted, int n_sorted) {
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kExtBlock + threadIdx.x;
     if (i >= count) return;
     const size_t p = (size_t)(i < n_sorted ? sorted[i] : W.queue[(size_t)qi * W.cap + i]);
-    V3 o, d;
-    int skip;
-    queue_ray<MODE>(S, W, p, gi, o, d, skip);
+    VertexRec* vr = W.verts + (size_t)gi * W.cap + p;
+    const VertexRec v = *vr;
+    const int light = v.shadow;
+    const V3 lc = light_origin(S, light);
+    const V3 d = normalize(sub(mk(v.x, v.y, v.z), lc));
     double mint;
-    const int hit = nearest_hit_grouped(S, o, d, skip, mint);
-    if (MODE == kGather) {
-        struct alignas(16) Tail {
-            double t;
-            int32_t hit, pad;
-        } tail = {mint, hit, 0};
-        *reinterpret_cast<Tail*>(&W.rays[p].t) = tail;  // one 16-byte store into the line just read
-    } else {
-        W.verts[(size_t)gi * W.cap + p].shadow = hit;
-    }
+    vr->shadow = nearest_hit_grouped(S, lc, d, light, mint);
 }
 
-// Shade the hits of queue `qi` at depth `depth`; survivors go to queue qi + 1.  KEYS: the sort key of
-// a survivor's new ray is stored at its queue position (W.keys was filled with the end key), which
-// spares the next scan's sort a pass over the rays.
-template <bool KEYS>
-__global__ void __launch_bounds__(kPushBlock) k_wf_shade(DScene S, WfState W, int qi, int depth) {
-    const int count = W.qcount[qi];
-    const int i = blockIdx.x * kPushBlock + threadIdx.x;
-    if ((int)(blockIdx.x * kPushBlock) >= count) return;
-    __shared__ uint4 s_tile[kPushBlock * 4];  // 64 bytes per thread: the waves' record tiles
-    uint4* tile = s_tile + (threadIdx.x >> 6) * 256;
-    bool alive = false;
-    size_t p = 0;
-    V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 0.0);
-    if (i < count) p = (size_t)W.queue[(size_t)qi * W.cap + i];
-    RayRec rr = wave_load_rays(W.rays, (uint32_t)p, i < count, tile);
-    VertexRec v;
-    v.x = v.y = v.z = 0.0, v.body = -1, v.shadow = -1;
-    if (i < count) {
-        const int hit = rr.hit;
-        if (hit >= 0) {
-            alive = true;
-            o = mk(rr.ox, rr.oy, rr.oz);
-            d = mk(rr.dx, rr.dy, rr.dz);
-            Draws dr;
-            dr.rng = load_rng(W, p);
-            dr.count = 0;
-            const DMat& m = S.mat[hit];
-            // the vertex before this one: the ray origin, or the camera-plane point for the first
-            const V3 prev = depth > 0 ? o : cam_point(S, W.xy[p], W.xy[W.cap + p]);
-            V3 point = shade_hit(S.geom[hit], m, dr, o, d, rr.t);
-            if (m.emits | ((m.material != kDiffuse) & same_point(point, prev))) W.need[p] = depth + 1;  // see trace_path_nee_compact
-            v.x = point.x, v.y = point.y, v.z = point.z, v.body = hit;
-            W.nrec[p] = depth + 1;
-            rr.ox = o.x, rr.oy = o.y, rr.oz = o.z, rr.dx = d.x, rr.dy = d.y, rr.dz = d.z;  // t and hit go stale; the next scan rewrites them
-            store_rng(W, p, dr.rng);
+// The first stage: camera ray and per-path RNG stream, then the scan and the shading of depth 0 as
+// k_wf_bounce does them (the rays leave the camera in pixel order, which is as coherent as a sort
+// would make them).  One wave to a block; grid (4 * owned tiles, iterations of the batch); path id
+// p = b * J + j with j = tile * 256 + place in the tile, and position p of the entries.  Queue 0 is
+// every path id of the batch in order, the few without a sample (outside the image or the row range,
+// past a short frame's end) included: they get no records and no shadow tasks, every later stage
+// passes them by, and their sample slot, which the accumulation never reads, is written as zero.
+template <bool KEYS, class PartitionT, class SlotFn>
+__device__ inline void wf_primary_body(const DScene& S, const PartitionT& P, SlotFn slot_of_fn, int first_it,
+                                       const double* __restrict__ xs, const double* __restrict__ ys,
+                                       const int32_t* __restrict__ row_start, const int32_t* __restrict__ npix,
+                                       double xstep, int xstride, WfState W, size_t J, int n_it, uint4* tile) {
+    const int lane = threadIdx.x;  // blocks of one wave
+    const int b = blockIdx.y;
+    const int q = blockIdx.x >> 2, ttid = (int)(blockIdx.x & 3u) * 64 + lane;
+    const int Wd = S.width, H = S.height;
+    const int slot = slot_of_fn(P, q, ttid, Wd, H);
+    const size_t p = (size_t)b * J + (size_t)q * kWfBlock + ttid;
+    const bool valid = slot >= 0 && slot < npix[b];
+    RayRec rr;
+    rr.ox = rr.oy = rr.oz = rr.dx = rr.dy = rr.dz = 0.0;
+    rr.s0 = rr.s1 = rr.s2 = rr.s3 = 0u;
+    double x = 0.0, y = 0.0, t = 0.0;
+    int hit = -1;
+    V3 eye_point = mk(0.0, 0.0, 0.0);
+    if (valid) {
+        const int32_t* rs = row_start + (size_t)b * (H + 1);
+        int r = slot / Wd;
+        while (slot >= rs[r + 1]) r++;
+        int c = slot - rs[r];
+        const int CK = (Wd + xstride - 1) / xstride;
+        if (S.flags & 4u) {
+            x = (double)c / (double)Wd;  // light_tracing.cpp:787
+        } else {
+            x = xs[((size_t)b * CK + c / xstride) * H + r];
+            for (int i = c % xstride; i > 0; --i) x += xstep;
         }
+        y = ys[(size_t)b * H + r];
+        V3 o = ld3(S.cam_o);
+        eye_point = cam_point(S, x, y);
+        V3 d = normalize(sub(eye_point, o));  // Camera::getRay main.cpp:154-157
+        rr.ox = o.x, rr.oy = o.y, rr.oz = o.z, rr.dx = d.x, rr.dy = d.y, rr.dz = d.z;
+        const Rng rng = rng_init(S.seed, (uint32_t)(first_it + b), kDomPixel, (uint32_t)slot);
+        rr.s0 = rng.s0, rr.s1 = rng.s1, rr.s2 = rng.s2, rr.s3 = rng.s3;
+        hit = nearest_hit_grouped(S, o, d, -1, t);
     }
-    wave_store_rays<3>(W.rays, (uint32_t)p, alive, rr, tile);
-    wave_store_verts(W.verts + (size_t)depth * W.cap, (uint32_t)p, alive, v, tile);
-    __shared__ int32_t s_push[kPushBlock / 64 + 1];
-    const int pos = queue_push(W.queue + (size_t)(qi + 1) * W.cap, W.qcount + qi + 1, alive, (int)p, s_push);
-    if (KEYS && alive) PT_NT1(ray_key<kGather>(S, o, d), W.keys + pos);
+    PT_NT1(x, W.xy + p);
+    PT_NT1(y, W.xy + W.cap + p);
+    PT_NT1(0, W.need + p);
+    PT_NT1((int32_t)p, W.queue + p);
+    if (!valid) {
+        PT_NT1(0, W.nrec + p);
+        __builtin_nontemporal_store(u32x4_nt{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4_nt*>(W.rays + p) + 3);  // the stream k_wf_light reads
+    }
+    wf_shade_and_store<KEYS, true>(S, W, 0, p, (uint32_t)p, valid, rr, hit, t, eye_point, tile);
+    if (blockIdx.x == 0 && b == 0 && lane == 0) W.qcount[0] = (int32_t)(J * (size_t)n_it);
 }
 
 constexpr int kShadowQueue0 = kMaxDepth + 1;  // queue index of the shadow tasks of vertex 0
@@ -618,11 +600,11 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
     if (active) {
         p = (size_t)W.queue[i];
         Draws dr;
-        dr.rng = load_rng(W, p);
+        dr.rng = rng_of(reinterpret_cast<const uint4*>(W.rays + p)[3]);  // the stream as the path's last bounce left it
         dr.count = 0;
         light = pick_light(S, dr);
         W.light[p] = light;
-        store_rng(W, p, dr.rng);
+        W.rng[p] = make_uint4(dr.rng.s0, dr.rng.s1, dr.rng.s2, dr.rng.s3);
         tasks = S.nee_emission_only ? W.need[p] : W.nrec[p];
     }
     __shared__ int32_t s_push[kPushBlock / 64 + 1];
@@ -634,7 +616,7 @@ __global__ void __launch_bounds__(kPushBlock) k_wf_light(DScene S, WfState W) {
             v->shadow = light;  // what the shadow scan reads
             if (KEYS) {
                 const V3 lc = light_origin(S, light);
-                key = ray_key<kShadow>(S, lc, normalize(sub(mk(v->x, v->y, v->z), lc)));  // the ray of queue_ray<kShadow>
+                key = ray_key<kShadow>(S, lc, normalize(sub(mk(v->x, v->y, v->z), lc)));  // the ray of k_wf_shadow
             }
         }
         const int pos = queue_push(W.queue + (size_t)(kShadowQueue0 + g) * W.cap, W.qcount + kShadowQueue0 + g, task, (int)p, s_push);
@@ -658,7 +640,7 @@ __global__ void __launch_bounds__(kWfBlock, 4) k_wf_nee_finish(DScene S, WfState
         const int light = W.light[p];
         const V3 lc = light_origin(S, light);
         Draws dr;
-        dr.rng = load_rng(W, p);
+        dr.rng = rng_of(W.rng[p]);
         dr.count = 0;
 #pragma unroll 1
         for (int gi = tasks - 1; gi >= 0; --gi) {

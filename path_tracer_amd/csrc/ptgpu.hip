@@ -291,14 +291,15 @@ __global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT 
 }
 
 // ---- wavefront pipeline: first stage (the other stages are in pt_wavefront.hpp) ---------------
+template <bool KEYS>
 __global__ void __launch_bounds__(ptw::kExtBlock) k_wf_primary(DScene S, Partition P, int first_it, int n_it,
                                                                 const double* __restrict__ xs, const double* __restrict__ ys,
                                                                 const int32_t* __restrict__ row_start,
                                                                 const int32_t* __restrict__ npix, double xstep, ptw::WfState W,
                                                                 size_t J) {
     __shared__ uint4 s_tile[64 * 4];
-    ptw::wf_primary_body(S, P, [](const Partition& Pp, int q, int tid, int Wd, int H) { return slot_of(Pp, q, tid, Wd, H); },
-                         first_it, xs, ys, row_start, npix, xstep, kXStride, W, J, n_it, s_tile);
+    ptw::wf_primary_body<KEYS>(S, P, [](const Partition& Pp, int q, int tid, int Wd, int H) { return slot_of(Pp, q, tid, Wd, H); },
+                               first_it, xs, ys, row_start, npix, xstep, kXStride, W, J, n_it, s_tile);
 }
 
 // ---- k_accumulate ------------------------------------------------------------------------
@@ -1286,9 +1287,8 @@ int ensure_wavefront_buffers(pt_scene* s) {
     W.rays = (ptw::RayRec*)s->d_wf.p;  // 256-byte aligned, like every allocation
     W.verts = (ptw::VertexRec*)(W.rays + cap);
     W.xy = (double*)(W.verts + cap * kMaxDepth);
-    uint32_t* u = (uint32_t*)(W.xy + 2 * cap);
-    W.rng = u;
-    int32_t* w = (int32_t*)(u + 4 * cap);
+    W.rng = (uint4*)(W.xy + 2 * cap);  // 16-byte aligned: cap is a multiple of 256
+    int32_t* w = (int32_t*)(W.rng + cap);
     W.nrec = w;
     W.light = W.nrec + cap;
     W.need = W.light + cap;
@@ -1321,18 +1321,17 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     const int nblk_push = (int)((J * (size_t)B + kPushBlock - 1) / kPushBlock);
     const int nblk_ext = (int)((J * (size_t)B + kExtBlock - 1) / kExtBlock);
     HIP_TRY(hipMemsetAsync(W.qcount, 0, 16 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_wf_primary, dim3(P.owned_tiles * 4, B), dim3(kExtBlock), 0, st, s->ds, P, it0, B, xs, ys, rs, npix, s->xstep, W, J);
-    // the rays of a queue are put in key order before the scan (not the primary rays, which
-    // k_wf_primary scans in pixel order)
-    // (the keys of a gather queue were written by the shading stage that filled it)
-    const int cap = (int)(J * (size_t)B);  // entries this batch can hold; the count is known on the device only
-    // The library sort takes its size from the host.  Only the first n entries of a queue are sorted,
-    // n from the count the same queue had in an earlier batch (plus a margin; everything while no
-    // count has arrived): a scan reads entry i from the sorted list when i < n and from the queue
-    // itself otherwise, so any n gives the same results and a poor guess only costs coherence.
-    auto sort_size = [&](int qi) -> int {
+    const int cap = (int)(J * (size_t)B);  // paths of this batch = positions of every depth's gather entries
+    // The library sort takes its size from the host.  The gather entries of a depth are one per position
+    // (dead ones carry the end key), so their sort covers the batch.  Of a shadow queue, whose count is
+    // known on the device only, the first n entries are sorted, n from the count the same queue had in an
+    // earlier batch (plus a margin; everything while no count has arrived): a scan reads entry i from the
+    // sorted list when i < n and from the queue itself otherwise, so any n gives the same results and a
+    // poor guess only costs coherence.
+    auto sort_size = [&](int mode, int qi) -> int {
         if (const char* f = getenv("PTGPU_SORT_FRACTION"))  // tests: a fixed part of the capacity, whatever the counts
             return (int)std::min<double>((double)cap, std::max(0.0, atof(f)) * (double)cap);
+        if (mode == kGather) return cap;
         const int before = s->wf_counts_host ? s->wf_counts_host[qi] : -1;  // may change under us; any value will do
         if (before < 0 || s->wf_counts_cap <= 0) return cap;
         const double frac = (double)before / (double)s->wf_counts_cap;
@@ -1343,7 +1342,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
     auto sorted_list = [&](int mode, int qi, int gi, int* n_sorted) -> const int32_t* {
         *n_sorted = 0;
         if (!s->wf_sort) return W.sorted;
-        const int n = sort_size(qi);
+        const int n = sort_size(mode, qi);
         const uint32_t* keys_in = mode == kShadow ? W.skeys + (size_t)gi * W.cap : W.keys;
         uint32_t* keys_out = (uint32_t*)s->d_wf_sort.p;
         void* tmp = (char*)s->d_wf_sort.p + ((W.cap * sizeof(uint32_t) + 255) & ~(size_t)255);
@@ -1361,18 +1360,19 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         *n_sorted = n;
         return W.sorted;
     };
-    for (int depth = 0; depth < kMaxDepth; ++depth) {
-        if (depth > 0) {  // k_wf_primary has scanned the camera rays
-            int n_sorted = 0;
-            const int32_t* list = sorted_list(kGather, depth, 0, &n_sorted);
-            hipLaunchKernelGGL((k_wf_extend<kGather>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, 0, list, n_sorted);
-        }
-        if (s->wf_sort && depth + 1 < kMaxDepth) {  // the next queue will be sorted: end keys everywhere, then the survivors' keys
-            HIP_TRY(hipMemsetAsync(W.keys, 0xFF, (size_t)cap * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_wf_shade<true>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
-        } else {
-            hipLaunchKernelGGL(k_wf_shade<false>, dim3(nblk_push), dim3(kPushBlock), 0, st, s->ds, W, depth, depth);
-        }
+    // depth 0: the camera rays, in pixel order; every stage writes the sort keys of the next depth's
+    // entries (its own threads' positions) when that depth will be sorted
+    if (s->wf_sort)
+        hipLaunchKernelGGL(k_wf_primary<true>, dim3(P.owned_tiles * 4, B), dim3(kExtBlock), 0, st, s->ds, P, it0, B, xs, ys, rs, npix, s->xstep, W, J);
+    else
+        hipLaunchKernelGGL(k_wf_primary<false>, dim3(P.owned_tiles * 4, B), dim3(kExtBlock), 0, st, s->ds, P, it0, B, xs, ys, rs, npix, s->xstep, W, J);
+    for (int depth = 1; depth < kMaxDepth; ++depth) {
+        int n_sorted = 0;
+        const int32_t* list = sorted_list(kGather, depth, 0, &n_sorted);
+        if (s->wf_sort && depth + 1 < kMaxDepth)
+            hipLaunchKernelGGL(k_wf_bounce<true>, dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, list, n_sorted, cap);
+        else
+            hipLaunchKernelGGL(k_wf_bounce<false>, dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, depth, list, n_sorted, cap);
     }
     if (s->estimator == PT_EST_NEE) {
         if (s->wf_sort) {
@@ -1384,7 +1384,7 @@ int render_wavefront(pt_scene* s, hipStream_t st, int it0, int B, const double* 
         for (int gi = kMaxDepth - 1; gi >= 0; --gi) {
             int n_sorted = 0;
             const int32_t* list = sorted_list(kShadow, kShadowQueue0 + gi, gi, &n_sorted);
-            hipLaunchKernelGGL((k_wf_extend<kShadow>), dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list, n_sorted);
+            hipLaunchKernelGGL(k_wf_shadow, dim3(nblk_ext), dim3(kExtBlock), 0, st, s->ds, W, kShadowQueue0 + gi, gi, list, n_sorted);
         }
         if (s->has_measured)
             hipLaunchKernelGGL(k_wf_nee_finish<true>, dim3(nblk), dim3(kWfBlock), 0, st, s->ds, W, samples, J);
