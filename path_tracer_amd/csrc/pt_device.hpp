@@ -1594,45 +1594,114 @@ PTD_INLINE V3 trace_path_nee_compact(const DScene& S, Draws& dr, bool valid, dou
 // when the light path has five vertices; any finite value there gives these results.)
 // The connections are made while the light path is traced, vertex by vertex, so its positions are
 // never stored: the order of the pairs does not matter, only the count per gather vertex.
-PTD_INLINE V3 trace_path_bidir(const DScene& S, Draws& dr, double x, double y, const Records& rec) {
-    int n = 0, need = 0;
+// A lane has connections to make only while its light path lives and only to its gather vertices up to
+// the deepest emitting one — none at all for most paths — so after every light-path step the
+// (lane, gather vertex) connections of the wave are dealt to its 64 lanes as in trace_path_nee_compact:
+// an owner publishes (lane, vertex, light) in a 16-bit LDS slot at the connection's rank, lane q takes
+// slot q, fetches the owner's light-path vertex through the lane crossbar and the gather vertex from
+// the owner's LDS records, runs the scan, and the owners count their hits out of the ballot.  Every
+// lane of the wave must call this (`valid` false for lanes without a pixel).
+PTD_INLINE V3 trace_path_bidir(const DScene& S, Draws& dr, bool valid, double x, double y, const Records& rec,
+                               uint16_t* __restrict__ wave_slots) {
+    int n = 0, need = 0, light = 0;
     unsigned twin = 0;
-    V3 o = ld3(S.cam_o);
-    V3 prev = cam_point(S, x, y);
-    V3 d = normalize(sub(prev, o));  // Camera::getRay main.cpp:154-157
+    V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 0.0);
+    if (valid) {
+        o = ld3(S.cam_o);
+        V3 prev = cam_point(S, x, y);
+        d = normalize(sub(prev, o));  // Camera::getRay main.cpp:154-157
 #pragma unroll 1
-    for (; n < kMaxDepth; ++n) {
-        double mint;
-        int hit = nearest_hit_any(S, o, d, mint);
-        if (hit < 0) break;
-        const DMat& m = S.mat[hit];
-        V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);
-        rec.put(n, point, hit);
-        const bool tw = (m.material != kDiffuse) & same_point(point, prev);
-        twin |= (tw ? 1u : 0u) << n;
-        if (m.emits | tw) need = n + 1;
-        prev = point;
+        for (; n < kMaxDepth; ++n) {
+            double mint;
+            int hit = nearest_hit_any(S, o, d, mint);
+            if (hit < 0) break;
+            const DMat& m = S.mat[hit];
+            V3 point = shade_hit(S.geom[hit], m, dr, o, d, mint);
+            rec.put(n, point, hit);
+            const bool tw = (m.material != kDiffuse) & same_point(point, prev);
+            twin |= (tw ? 1u : 0u) << n;
+            if (m.emits | tw) need = n + 1;
+            prev = point;
+        }
+        light = pick_light(S, dr);
+        // light->shape->center through a Shape* is (0,0,0) unless the scene asks for the real centre;
+        // getNormal is virtual and uses the shape's own centre (bidirectional.cpp:402-404)
+        o = light_origin(S, light);
+        d = random_in_hemisphere(dr, shape_normal(S.geom[light], o));
     }
-    const int light = pick_light(S, dr);
-    // light->shape->center through a Shape* is (0,0,0) unless the scene asks for the real centre;
-    // getNormal is virtual and uses the shape's own centre (bidirectional.cpp:402-404)
-    o = light_origin(S, light);
-    d = random_in_hemisphere(dr, shape_normal(S.geom[light], o));
+    const int lane = rec.tid & 63;
+    const int wave_tid0 = rec.tid & ~63;
+    // a path without an emitting vertex is black whatever its light path does, and nothing reads the
+    // random stream after the light path: such lanes trace none
+    bool shooting = valid & (need > 0);
     unsigned seen = 0;  // three bits per gather vertex: the number of light-path vertices that see it
-    DScene T = S;  // the second phase: see refresh_scan_controls
+    DScene T = S;  // the light-path scans: see refresh_scan_controls
     refresh_scan_controls(T);
 #pragma unroll 1
     for (int ns = 0; ns < kMaxDepth; ++ns) {
-        double mint;
-        int hit = nearest_hit_any(T, o, d, mint);
-        if (hit < 0) break;
-        const V3 sp = shade_hit(S.geom[hit], S.mat[hit], dr, o, d, mint);
+        // the connection scans are run by other lanes than the light-path scans, and by more lanes in a
+        // later step than in the last round of this one: their controls are derived anew in every step,
+        // here, where the whole wave is present
+        DScene C = S;
+        refresh_scan_controls(C);
+        V3 sp = mk(0.0, 0.0, 0.0);
+        if (shooting) {
+            double mint;
+            int hit = nearest_hit_any(T, o, d, mint);
+            shooting = hit >= 0;
+            if (shooting) sp = shade_hit(S.geom[hit], S.mat[hit], dr, o, d, mint);
+        }
+        if (PTD_MASK(shooting) == 0) break;
+        const int stop = shooting ? need : 0;
+        lanemask owners[kMaxDepth];
+        int first[kMaxDepth + 1];
+        first[0] = 0;
+#pragma unroll
+        for (int g = 0; g < kMaxDepth; ++g) {
+            owners[g] = PTD_MASK(stop > g);
+            first[g + 1] = first[g] + __builtin_popcountll(owners[g]);
+        }
+        const int total = first[kMaxDepth];
 #pragma unroll 1
-        for (int g = 0; g < need; ++g) {
-            const V3 bd = normalize(sub(rec.point(g), sp));  // bi_ray :415-417
-            double t;
-            const int h = nearest_hit<false>(T, sp, bd, light, t);
-            seen += (h == rec.body(g) ? 1u : 0u) << (3 * g);  // :435-437
+        for (int base = 0; base < total; base += 64) {
+#pragma unroll
+            for (int g = 0; g < kMaxDepth; ++g) {
+                if (first[g + 1] > base && first[g] < base + 64) {
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(owners[g] >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)owners[g], 0u));
+                    const int q = first[g] + below - base;
+                    if ((stop > g) & ((unsigned)q < 64u)) wave_slots[q] = (uint16_t)(lane | (g << 6) | (light << 9));
+                }
+            }
+            // slots written and read by lanes of one wave, in program order: see trace_path_nee_compact
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            bool lit = false;
+            // every lane reads a slot (those past the count a stale one) and fetches the owner's light-path
+            // vertex through the lane crossbar, which needs owner and taker both active
+            const unsigned slot = wave_slots[lane];
+            const V3 sp_o = mk(lane_read(sp.x, (int)(slot & 63u)), lane_read(sp.y, (int)(slot & 63u)), lane_read(sp.z, (int)(slot & 63u)));
+            if (base + lane < total) {
+                const int g = (int)((slot >> 6) & 7u), lt = (int)(slot >> 9);
+                const int owner = wave_tid0 | (int)(slot & 63u);
+                const V3 bd = normalize(sub(rec.point_of(g, owner), sp_o));  // bi_ray :415-417
+                double t;
+                const int h = nearest_hit<false>(C, sp_o, bd, lt, t);
+                lit = h == rec.body_of(g, owner);  // :435-437
+            }
+            const lanemask lit_mask = PTD_MASK(lit);
+#pragma unroll
+            for (int g = 0; g < kMaxDepth; ++g) {
+                if (first[g + 1] > base && first[g] < base + 64) {
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(owners[g] >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)owners[g], 0u));
+                    const int q = first[g] + below - base;
+                    if ((stop > g) & ((unsigned)q < 64u)) seen += (unsigned)((lit_mask >> q) & 1ull) << (3 * g);
+                }
+            }
+            // the slots are rewritten by the next round: its stores must stay behind this round's loads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         }
     }
     V3 L = mk(0.0, 0.0, 0.0);

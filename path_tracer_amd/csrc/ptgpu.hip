@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT 
     constexpr int kTraceBlock = trace_block(EST), kTraceParts = kBlock / kTraceBlock;
     __shared__ double s_pts[EST == kEstPT ? 1 : (COMPACT ? kMaxDepth - 1 : kMaxDepth) * 3 * kTraceBlock];
     __shared__ int8_t s_bod[kMaxDepth * kTraceBlock];
-    __shared__ uint16_t s_slots[COMPACT ? kTraceBlock : 1];
+    __shared__ uint16_t s_slots[COMPACT || EST == kEstBidir ? kTraceBlock : 1];
     const int tid = threadIdx.x;
     // blockIdx.x = (owned tile << gl) + g, iteration b = (blockIdx.y << gl) + g: see launch_trace
     const int gl = P.group_log2;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT 
     if (COMPACT) {
         rgb = trace_path_nee_compact(S, dr, valid, x, y, rec, s_slots + (tid & ~63));
     } else if (EST == kEstBidir) {
-        if (valid) rgb = trace_path_bidir(S, dr, x, y, rec);
+        rgb = trace_path_bidir(S, dr, valid, x, y, rec, s_slots + (tid & ~63));
     } else if (valid) {
         PathResult R = trace_path<EST, MEASURED, true>(S, dr, x, y, rec);
         rgb = R.rgb;
