@@ -28,6 +28,22 @@ def test_tiles_partition_the_image(W, H, world):
     assert max(counts) - min(counts) <= 1 and sum(counts) == tiles
 
 
+@pytest.mark.parametrize("W,H,world", [(1024, 768, 8), (1024, 768, 4), (3840, 2160, 8), (2048, 1536, 2)])
+def test_a_ranks_tiles_do_not_line_up_in_columns(W, H, world):
+    # frames whose tile rows hold a multiple of `world` tiles: numbered straight along the rows, a rank
+    # would own the same tile columns in every tile row (and render a fixed set of vertical stripes); with
+    # every tile row shifted by one column a rank meets every tile column equally often
+    tiles_x, tiles_y = W // ptd.TILE_W, H // ptd.TILE_H
+    assert tiles_x % world == 0
+    owner = ptd.tile_owner(W, H, world)[:: ptd.TILE_H, :: ptd.TILE_W]  # (tiles_y, tiles_x)
+    for r in range(world):
+        per_column = (owner == r).sum(axis=0)
+        assert per_column.min() >= tiles_y // world and per_column.max() <= -(-tiles_y // world)
+    # and the numbering is the one pt_set_partition documents: number ty*tiles_x + c sits at column (c + ty) % tiles_x
+    ty, c = 5, 3
+    assert owner[ty, (c + ty) % tiles_x] == (ty * tiles_x + c) % world
+
+
 def _worker(rank, world, port, W, H, frame_path, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
