@@ -488,8 +488,17 @@ PTD_INLINE void wf_shade_and_store(const DScene& S, const WfState& W, int depth,
 // Depth >= 1: one path per thread over the n_entries positions of the depth's entries, the first
 // n_sorted of them in the order of `sorted`, the rest in their own.  One wave to a block: nothing is
 // shared between waves, and a block of one ends as soon as its own rays are done.
+// Six waves per SIMD: the compiler then spills nine of the kernel's 89 vector registers, in the shading
+// part, which a path passes once; the scan, whose scalar loads want the waves, keeps its registers
+// (9.48e8 -> 9.58e8 paths/s on the 10 000-body scene; seven waves spill 17 and lose: 9.38e8).
+#ifndef PT_BOUNCE_WAVES
+#define PT_BOUNCE_WAVES 6
+#endif
+#ifndef PT_SHADOW_WAVES
+#define PT_SHADOW_WAVES 6
+#endif
 template <bool KEYS>
-__global__ void __launch_bounds__(kExtBlock) k_wf_bounce(DScene S, WfState W, int depth, const int32_t* __restrict__ sorted, int n_sorted,
+__global__ void __launch_bounds__(kExtBlock, PT_BOUNCE_WAVES) k_wf_bounce(DScene S, WfState W, int depth, const int32_t* __restrict__ sorted, int n_sorted,
                                                          int n_entries) {
     const size_t i = (size_t)blockIdx.x * kExtBlock + threadIdx.x;
     if ((size_t)blockIdx.x * kExtBlock >= (size_t)n_entries) return;  // whole waves only: the record moves below are wave-wide
@@ -508,7 +517,7 @@ __global__ void __launch_bounds__(kExtBlock) k_wf_bounce(DScene S, WfState W, in
 
 // The shadow ray towards vertex gi of every task of queue qi (next_event.cpp:405-407): from the light's
 // origin, the light excluded from the scan; the vertex record receives the body it hit.
-__global__ void __launch_bounds__(kExtBlock) k_wf_shadow(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ sorted, int n_sorted) {
+__global__ void __launch_bounds__(kExtBlock, PT_SHADOW_WAVES) k_wf_shadow(DScene S, WfState W, int qi, int gi, const int32_t* __restrict__ sorted, int n_sorted) {
     const int count = W.qcount[qi];
     const int i = blockIdx.x * kExtBlock + threadIdx.x;
     if (i >= count) return;

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT 
 
 // ---- wavefront pipeline: first stage (the other stages are in pt_wavefront.hpp) ---------------
 template <bool KEYS>
-__global__ void __launch_bounds__(ptw::kExtBlock) k_wf_primary(DScene S, Partition P, int first_it, int n_it,
+__global__ void __launch_bounds__(ptw::kExtBlock, PT_BOUNCE_WAVES) k_wf_primary(DScene S, Partition P, int first_it, int n_it,
                                                                 const double* __restrict__ xs, const double* __restrict__ ys,
                                                                 const int32_t* __restrict__ row_start,
                                                                 const int32_t* __restrict__ npix, double xstep, ptw::WfState W,
