@@ -305,27 +305,37 @@ __global__ void __launch_bounds__(ptw::kExtBlock, PT_BOUNCE_WAVES) k_wf_primary(
 // ---- k_accumulate ------------------------------------------------------------------------
 // buffer[i] += sample for every iteration whose frame reaches running index i
 // (main.cpp:362), in iteration order.
+// A block walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The accumulation of a batch runs on its
+// own stream beside the estimator kernel of the next batch, and what it takes from that kernel is
+// nearly its own duration when it runs flat out (without it the 15-body scene renders 3.5 % faster):
+// with one block per tile it pulls 5 TB/s for 0.65 ms and the estimator's waves wait on their table
+// loads and sample stores meanwhile.  512 blocks, two per compute unit, spread the same traffic over
+// a longer time: C2 8.78e9 -> 8.91e9, C4 8.77e9 -> 8.90e9, main32 9.98e9 -> 1.01e10 paths/s (64 blocks
+// make the accumulation longer than the batch it trails).
+constexpr int kAccumulateBlocks = 512;
 __global__ void __launch_bounds__(kBlock) k_accumulate(Partition P, int W, int H, int B,
                                                        const int32_t* __restrict__ npix,
                                                        const double* __restrict__ samples, size_t sample_stride,
                                                        double* __restrict__ accum) {
     const int tid = threadIdx.x;
-    const int slot = slot_of(P, blockIdx.x, tid, W, H);
-    if (slot < 0) return;
-    const size_t j = (size_t)blockIdx.x * kBlock + tid;
-    double* a = accum + (size_t)slot * 3;
-    double ax = a[0], ay = a[1], az = a[2];
-    for (int b = 0; b < B; ++b) {
-        if (slot < npix[b]) {
-            const double* s = samples + (size_t)b * 3 * sample_stride + j;
-            ax += s[0];
-            ay += s[sample_stride];
-            az += s[2 * sample_stride];
+    for (int q = blockIdx.x; q < P.owned_tiles; q += gridDim.x) {
+        const int slot = slot_of(P, q, tid, W, H);
+        if (slot < 0) continue;
+        const size_t j = (size_t)q * kBlock + tid;
+        double* a = accum + (size_t)slot * 3;
+        double ax = a[0], ay = a[1], az = a[2];
+        for (int b = 0; b < B; ++b) {
+            if (slot < npix[b]) {
+                const double* s = samples + (size_t)b * 3 * sample_stride + j;
+                ax += s[0];
+                ay += s[sample_stride];
+                az += s[2 * sample_stride];
+            }
         }
+        a[0] = ax;
+        a[1] = ay;
+        a[2] = az;
     }
-    a[0] = ax;
-    a[1] = ay;
-    a[2] = az;
 }
 
 // ---- tile exchange -----------------------------------------------------------------------
@@ -1764,7 +1774,9 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
         s->ev_used += 2;
         HIP_TRY(hipEventRecord(s->ev_trace[q], st));
         HIP_TRY(hipStreamWaitEvent(s->st_accum, s->ev_trace[q], 0));
-        hipLaunchKernelGGL(k_accumulate, dim3(P.owned_tiles), dim3(kBlock), 0, s->st_accum, P, W, H, B, npix, samples, J, accum_dev);
+        // beside the estimator of the next batch: few blocks that walk the tiles (see kAccumulateBlocks)
+        hipLaunchKernelGGL(k_accumulate, dim3(std::min(P.owned_tiles, kAccumulateBlocks)), dim3(kBlock), 0, s->st_accum, P, W, H, B, npix,
+                           samples, J, accum_dev);
         HIP_TRY(hipEventRecord(s->ev_acc[q], s->st_accum));
         HIP_TRY(hipGetLastError());
     }
