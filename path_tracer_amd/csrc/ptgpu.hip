@@ -201,7 +201,9 @@ void launch_frame_layout(hipStream_t st, uint64_t seed, int W, int H, int first_
 // COMPACT selects trace_path_nee_compact (NEE scenes whose direct term is dead everywhere): the
 // shadow tasks of a wave are dealt to its lanes through 64 two-byte LDS slots per wave.  That form
 // keeps four positions per path in LDS (26 368 B per block) and fits 80 VGPRs: six blocks per CU.
-// The path-tracing kernel keeps no positions and fits 64 VGPRs: eight.
+// The bidirectional kernel deals its connections through the same kind of slots (trace_path_bidir) and
+// keeps all five positions: five blocks.  The path-tracing kernel keeps no positions and fits 64
+// VGPRs: eight waves per SIMD, in one-wave blocks (trace_block).
 template <int EST, bool MEASURED, bool COMPACT = false>
 __global__ void __launch_bounds__(trace_block(EST), EST == kEstPT ? 8 : COMPACT ? 6 : 5) k_trace(DScene S, Partition P, int first_it, int n_it, const double* __restrict__ xs,
                                                   const double* __restrict__ ys, const int32_t* __restrict__ row_start,
