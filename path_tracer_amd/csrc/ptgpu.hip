@@ -1788,7 +1788,8 @@ int pt_render_device(pt_scene* s, int first_iteration, int n_iterations, double*
     double owned_pixels = 0;
     for (int q = 0; q < P.owned_tiles; ++q) {
         const int tile = q * P.world + P.rank;
-        const int x0 = (tile % P.tiles_x) * P.tile_w, y0 = (tile / P.tiles_x) * P.tile_h;
+        const int ty = tile / P.tiles_x;
+        const int x0 = ((tile - ty * P.tiles_x + ty) % P.tiles_x) * P.tile_w, y0 = ty * P.tile_h;  // as slot_of places the tile
         const int y1 = std::min(std::min(y0 + P.tile_h, H), P.row_hi), y00 = std::max(y0, P.row_lo);
         owned_pixels += (double)std::max(0, std::min(P.tile_w, W - x0)) * (double)std::max(0, y1 - y00);
     }
