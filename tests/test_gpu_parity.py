@@ -187,6 +187,8 @@ def test_partition_tiles_sum_to_whole():
             from path_tracer_amd import distributed as ptdist
 
             assert not (part != 0).any(axis=2)[~ptdist.owned_mask(W, H, rank, world)].any()  # host and device agree on ownership
+            # the path count a handle reports is that of the pixels it owns (100 is no multiple of the tile width)
+            assert r.stats()["paths"] == 3 * int(ptdist.owned_mask(W, H, rank, world).sum())
             owned += (part != 0).any(axis=2)
             acc += part
             r.close()
